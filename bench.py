@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — stage-1 brute-force top-k throughput on MI355X (the hot path of
+BASELINE.json's north_star; workload = configs[3]: synthetic 10M x 768 fp16
+corpus, batch-64 queries, top-1000, row-sharded over N GPUs with one RCCL
+all-gather + merge per batch).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one batch of 64 queries searched against the whole corpus: local
+shard scan + exact top-k on every rank, all-gather of the partial lists, merge.
+Corpus and queries are resident in HBM before the timed region.  The total
+corpus is fixed as N grows (strong scaling: the metric is quoted "@10Mx768
+corpus, 1/2/4/8 GPU").
+
+One JSON line on rank 0.  Besides the driver's contract it carries
+  roofline      the fused scan+filter kernel: algorithmic bytes per launch
+                (shard rows x padded dim x 2 B, the corpus read once) / its mean
+                duration measured with HIP events on the launch stream
+  cpu_baseline  the same search on the host cores (oracle.ip_topk_blas: blocked
+                SGEMM + partial sort, what faiss-cpu IndexFlatIP does) on a
+                bounded row sample, scaled to the full corpus.  N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="total corpus rows")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    return ap.parse_args()
+
+
+def gen_rows(torch, n, d, seed, dtype, device):
+    """Synthetic unit-norm rows, generated on the GPU in blocks."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((n, d), generator=g, device=device, dtype=torch.float32)
+    x = x / (x.norm(dim=1, keepdim=True) + 1e-8)
+    return x.to(dtype)
+
+
+def cpu_baseline(args, torch):
+    import numpy as np
+    from oracle import oracle
+    n = min(args.cpu_sample_rows, args.rows)
+    rng = np.random.default_rng(1234)
+    c = rng.standard_normal((n, args.dim), dtype=np.float32)
+    c /= (np.linalg.norm(c, axis=1, keepdims=True) + 1e-8)
+    q = rng.standard_normal((args.batch, args.dim), dtype=np.float32)
+    q /= (np.linalg.norm(q, axis=1, keepdims=True) + 1e-8)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    k = min(args.k, n)
+    oracle.ip_topk_blas(c, q, k)  # warm-up (BLAS thread pool, page faults)
+    reps, t_total = 0, 0.0
+    while t_total < 10.0 and reps < 50:
+        t0 = time.perf_counter()
+        oracle.ip_topk_blas(c, q, k)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    t = t_total / reps
+    scale = args.rows / n
+    return {
+        "value": args.batch / (t * scale),
+        "unit": "queries/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"{n} of {args.rows} rows x {args.dim} fp32, batch {args.batch}, top-{k}; "
+                   f"{reps} reps of {t * 1e3:.1f} ms, scaled x{scale:.1f} to the full corpus"),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    if args.gpus != world:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+
+    from tristage_rag_amd.index import FlatIPIndex
+    from tristage_rag_amd.sharded import ShardedFlatIPIndex, shard_bounds
+
+    # ---- build the (sharded) index; nothing here is timed
+    lo, hi = shard_bounds(args.rows, world, rank)
+    local = FlatIPIndex(args.dim, dtype=args.dtype, device=local_rank)
+    local.reserve(max(hi - lo, 1))
+    blk = 500_000
+    for r0 in range(lo, hi, blk):
+        n = min(blk, hi - r0)
+        local.add(gen_rows(torch, n, args.dim, 1234 + r0 // blk, tdt, device))
+    if world > 1:
+        index = ShardedFlatIPIndex(args.dim, args.rows, dtype=args.dtype, device=local_rank,
+                                   local_index=local)
+    else:
+        index = local
+    queries = [gen_rows(torch, args.batch, args.dim, 4321 + i, tdt, device) for i in range(4)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        return index.search(queries[i % len(queries)], args.k)
+
+    for i in range(args.warmup):
+        step(i)
+    local.set_profiling(True)
+    local.timings(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        D, I = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = local.timings(reset=True)
+    info = local.last_search_info()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (this rank's shard)
+    esize = 4 if args.dtype == "f32" else 2
+    gran = 64 if args.dtype == "f32" else 128
+    dpad = -(-args.dim // gran) * gran
+    shard_rows = hi - lo
+    alg_bytes = float(-(-shard_rows // 32) * 32) * dpad * esize
+    scan_ms, scan_cnt = tm["filter_scan"] if tm["filter_scan"][1] else tm["dense"]
+    kernel = "scan_kernel<filter>" if tm["filter_scan"][1] else "dense path (scan+select)"
+    roof = None
+    if scan_cnt:
+        avg_ms = scan_ms / scan_cnt
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.rows // world}x{args.dim}x{args.dtype}")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+                "avg_kernel_ms": round(avg_ms, 4), "launches": scan_cnt,
+                "algorithmic_bytes_per_launch": alg_bytes}
+
+    if rank == 0:
+        out = {
+            "metric": "end-to-end queries/sec @10Mx768 corpus (stage-1 exact top-k)",
+            "value": round(args.batch * args.steps / elapsed, 2),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": (f"synthetic {args.rows}x{args.dim} {args.dtype} corpus, batch-{args.batch} "
+                                    f"queries, stage-1 exact top-{args.k}, row-sharded over {world} GPU(s)"
+                                    + (", RCCL all-gather + HIP merge" if world > 1 else "")),
+                       "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
+                       "search_path": info["path"], "max_candidates_per_query": info["max_candidates"],
+                       "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]}},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, torch)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/*
+ * tristage.h — C ABI of the MI355X-native retrieval hot path of TriStage-RAG.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of
+ * its own: its native seam is the duck-typed FAISS index object held in
+ * Stage1Retriever.faiss_index (reference src/stage1_retriever.py:126) plus
+ * the per-candidate torch MaxSim in ColBERTScorer (src/stage2_rescorer.py:167-201).
+ * Each entry point below names the reference call site it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative
+ *     ts_status code, and ts_last_error() gives a thread-local message;
+ *   - "device pointer" = HIP device memory on the index's device (e.g. a torch
+ *     tensor's data_ptr()); `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream);
+ *   - the library owns the corpus memory after ts_index_add; the caller owns
+ *     every output buffer; a handle is freed only by ts_index_destroy;
+ *   - threading: ts_index_search on a built index may not run concurrently on
+ *     ONE handle (it uses the handle's workspace); use one handle per GPU rank.
+ *     add / reset / destroy need exclusive access.
+ */
+#ifndef TRISTAGE_H_
+#define TRISTAGE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_ABI_VERSION 1
+
+typedef struct ts_index ts_index; /* opaque */
+
+enum ts_status {
+  TS_OK = 0,
+  TS_ERR_INVALID = -1,   /* bad argument */
+  TS_ERR_HIP = -2,       /* a HIP runtime call failed */
+  TS_ERR_OOM = -3,       /* device allocation failed */
+  TS_ERR_EMPTY = -4,     /* search on an index with no rows
+                            (reference: ValueError "No documents indexed",
+                            src/stage1_retriever.py:370-371) */
+  TS_ERR_UNSUPPORTED = -5
+};
+
+enum ts_dtype { TS_F32 = 0, TS_F16 = 1, TS_BF16 = 2 };
+
+enum ts_metric { TS_METRIC_INNER_PRODUCT = 0 };
+
+/* ts_index_add / ts_index_search flags */
+#define TS_FLAG_HOST_PTR 1u     /* `rows` / `queries` / outputs are host memory */
+#define TS_FLAG_NO_FILTER 2u    /* search: force the dense (materialise+select) path */
+#define TS_FLAG_NORMALIZE 4u    /* add: L2-normalise rows x/(|x|+1e-8) on device first
+                                   (reference src/stage1_retriever.py:285-288) */
+
+/* ---- index lifetime ------------------------------------------------------
+ * replaces faiss.IndexFlatIP(d) (reference src/stage1_retriever.py:263,276).
+ * storage_dtype: element type the corpus is kept in (TS_F32 = FAISS-exact
+ * storage; TS_F16 / TS_BF16 halve the bytes scanned).                        */
+int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metric,
+                    int32_t device, ts_index** out);
+int ts_index_destroy(ts_index* h);
+/* drop all rows, keep the allocation */
+int ts_index_reset(ts_index* h);
+/* pre-size the corpus allocation for `nrows` rows in total */
+int ts_index_reserve(ts_index* h, int64_t nrows);
+
+/* ---- add -----------------------------------------------------------------
+ * replaces faiss_index.add(float32[n,d]) (src/stage1_retriever.py:270,277,313).
+ * rows: row-major [n, dim] of rows_dtype (device pointer unless
+ * TS_FLAG_HOST_PTR).  Rows are appended; ids are assigned consecutively.    */
+int ts_index_add(ts_index* h, const void* rows, int64_t n, int32_t rows_dtype,
+                 uint32_t flags, void* stream);
+
+/* ---- search --------------------------------------------------------------
+ * replaces faiss_index.search(float32[B,d], k) (src/stage1_retriever.py:380):
+ * exact inner product of each query against every row; out_scores[B,k]
+ * sorted descending, ties by ascending id; out_ids[B,k] int64; when k exceeds
+ * the row count the tail is padded with id -1 / score -FLT_MAX (FAISS's
+ * convention, which the reference filters at src/stage1_retriever.py:383).
+ * Ids are row numbers plus the offset set by ts_index_set_id_offset.
+ * Synchronous with respect to `stream` on return.                            */
+int ts_index_search(ts_index* h, const void* queries, int32_t nq,
+                    int32_t q_dtype, int32_t k, float* out_scores,
+                    int64_t* out_ids, uint32_t flags, void* stream);
+
+/* ---- introspection -------------------------------------------------------
+ * faiss_index.ntotal / .d                                                    */
+int64_t ts_index_ntotal(const ts_index* h);
+int32_t ts_index_dim(const ts_index* h);
+int32_t ts_index_dtype(const ts_index* h);
+/* row-shard support: ids reported by search = local row + offset            */
+int ts_index_set_id_offset(ts_index* h, int64_t offset);
+/* copy rows [row0, row0+n) back out as row-major float32 (host or device):
+ * used by save_index (reference src/stage1_retriever.py:421-441)            */
+int ts_index_reconstruct(ts_index* h, int64_t row0, int64_t n, float* out,
+                         uint32_t flags, void* stream);
+/* counters of the last search on this handle: [0] path taken (0 dense,
+ * 1 filter, 2 filter-then-dense fallback), [1] max candidates per query,
+ * [2] sample rows, [3] sample rank m                                         */
+int ts_index_last_search_info(const ts_index* h, int64_t info[4]);
+
+/* Per-phase device timing of searches, measured with HIP events recorded on the
+ * search's own stream (bench.py's roofline leg).  Phases: 0 query prep,
+ * 1 sample scan, 2 thresholds, 3 fused scan+filter (the dominant kernel),
+ * 4 candidate select, 5 dense path (scan+select), 6-7 unused.  ms[i] is the sum
+ * over counts[i] occurrences since the last reset.                           */
+int ts_index_set_profiling(ts_index* h, int32_t on);
+int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t reset);
+
+/* ---- merge of per-shard partial top-k lists --------------------------------
+ * New for the row-sharded multi-GPU path: `scores`/`ids` are
+ * device arrays [nlists, nq, k] (e.g. the output of an RCCL all-gather of each
+ * rank's ts_index_search result); writes the global top-k [nq, k] in the same
+ * canonical order.  Entries with id < 0 are padding and ignored.            */
+int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
+                  int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
+                  int32_t device, void* stream);
+
+/* ---- stage-2 MaxSim ------------------------------------------------------
+ * replaces ColBERTScorer._maxsim_score / _colbert_score applied per candidate
+ * (reference src/stage2_rescorer.py:167-201, loop at :268-276).
+ * q:       device [Lq, H] token embeddings of the query (dtype)
+ * docs:    device [sum(Ld_i), H] token embeddings of all candidates, packed
+ * doc_off: device int32 [n_docs+1] row offsets into docs
+ * mode:    0 = maxsim (mean_i max_j cos), 1 = colbert (softmax-weighted)
+ * out:     device float32 [n_docs]                                           */
+int ts_maxsim(const void* q, int32_t Lq, const void* docs,
+              const int32_t* doc_off, int32_t n_docs, int32_t H, int32_t dtype,
+              int32_t mode, float* out, int32_t device, void* stream);
+
+/* ---- misc ---------------------------------------------------------------- */
+const char* ts_last_error(void);
+int ts_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRISTAGE_H_ */

@@ -1,0 +1,208 @@
+"""GPU parity: the HIP stage-1 path (through the C ABI) vs the CPU oracle on
+identical, storage-quantised inputs.  Bar: bit-exact top-k ids, scores within
+1e-3 (BASELINE.json north_star); accepted id swaps are only those the float64
+oracle itself cannot separate (helpers.check_topk)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import check_topk, make_corpus
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _index(d, dtype, rows=None):
+    from tristage_rag_amd.index import FlatIPIndex
+    idx = FlatIPIndex(d, dtype=dtype)
+    if rows is not None:
+        idx.add(rows)
+    return idx
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("n,d,k,B", [(1000, 96, 10, 5), (5183, 384, 100, 64), (33, 40, 7, 1),
+                                      (4097, 128, 1000, 33)])
+def test_dense_path_matches_oracle(dtype, n, d, k, B):
+    corpus = make_corpus(n, d, seed=1234, dtype=dtype)
+    queries = make_corpus(B, d, seed=4321, dtype=dtype)
+    idx = _index(d, dtype, corpus)
+    assert idx.ntotal == n
+    D, I = idx.search(queries, k)
+    assert idx.last_search_info()["path"] == "dense"
+    check_topk(D, I, corpus, queries, k)
+    idx.close()
+
+
+def test_more_than_64_queries_and_k_larger_than_n():
+    corpus = make_corpus(50, 64, dtype="f16")
+    queries = make_corpus(150, 64, seed=5, dtype="f16")
+    idx = _index(64, "f16", corpus)
+    D, I = idx.search(queries, 100)          # k > N: FAISS pads with -1
+    check_topk(D, I, corpus, queries, 100)
+    assert (I[:, 50:] == -1).all()
+    idx.close()
+
+
+def test_exact_ties_are_ordered_by_ascending_id():
+    rng = np.random.default_rng(3)
+    base = make_corpus(64, 128, seed=9, dtype="f16")
+    corpus = base[rng.integers(0, 64, size=3000)]      # heavy duplication
+    queries = make_corpus(8, 128, seed=10, dtype="f16")
+    idx = _index(128, "f16", corpus)
+    D, I = idx.search(queries, 500)
+    D0, I0 = oracle.ip_topk(corpus, queries, 500)
+    # within a run of equal GPU scores the ids must ascend
+    for q in range(8):
+        for r in range(1, 500):
+            if D[q, r] == D[q, r - 1]:
+                assert I[q, r] > I[q, r - 1]
+    check_topk(D, I, corpus, queries, 500)
+    idx.close()
+
+
+@pytest.mark.parametrize("dtype,n,d,k,B", [("f16", 100_000, 128, 100, 64), ("bf16", 70_001, 256, 10, 7),
+                                            ("f16", 300_000, 64, 1000, 64), ("f32", 65_536, 64, 50, 32)])
+def test_filter_path_matches_oracle_and_dense_path(dtype, n, d, k, B):
+    corpus = make_corpus(n, d, seed=1234, dtype=dtype)
+    queries = make_corpus(B, d, seed=4321, dtype=dtype)
+    idx = _index(d, dtype, corpus)
+    D, I = idx.search(queries, k)
+    info = idx.last_search_info()
+    assert info["path"] == "filter", info
+    assert k <= info["max_candidates"] <= 16384
+    check_topk(D, I, corpus, queries, k)
+    D2, I2 = idx.search(queries, k, exact_dense=True)   # same kernel arithmetic, no filter
+    assert idx.last_search_info()["path"] == "dense"
+    assert np.array_equal(I, I2)
+    assert np.array_equal(D, D2)
+    idx.close()
+
+
+def test_filter_falls_back_when_candidates_overflow():
+    # every row identical: every score ties, the candidate lists overflow and the
+    # exact dense path must take over (ids 0..k-1 by the tie rule)
+    row = make_corpus(1, 128, seed=1, dtype="f16")
+    corpus = np.repeat(row, 40_000, axis=0)
+    queries = make_corpus(3, 128, seed=2, dtype="f16")
+    idx = _index(128, "f16", corpus)
+    D, I = idx.search(queries, 20)
+    assert idx.last_search_info()["path"] == "filter+dense-fallback"
+    assert (I == np.arange(20)[None, :]).all()
+    idx.close()
+
+
+def test_incremental_add_unaligned_and_reconstruct():
+    d = 72
+    parts = [make_corpus(n, d, seed=s, dtype="bf16") for n, s in ((45, 1), (1000, 2), (7, 3), (1, 4))]
+    idx = _index(d, "bf16")
+    for p in parts:
+        idx.add(p)
+    corpus = np.concatenate(parts, 0)
+    assert idx.ntotal == corpus.shape[0]
+    np.testing.assert_array_equal(idx.reconstruct_n(0, idx.ntotal), corpus)
+    queries = make_corpus(9, d, seed=77, dtype="bf16")
+    D, I = idx.search(queries, 30)
+    check_topk(D, I, corpus, queries, 30)
+    idx.reset()
+    assert idx.ntotal == 0
+    with pytest.raises(ValueError, match="No documents indexed"):
+        idx.search(queries, 5)
+    idx.close()
+
+
+def test_add_rounds_float32_rows_to_storage_dtype_and_normalizes():
+    rng = np.random.default_rng(0)
+    raw = rng.standard_normal((300, 100)).astype(np.float32) * 3.0
+    idx = _index(100, "f16")
+    idx.add(raw, normalize=True)     # x/(|x|+1e-8) on device, reference :285-288
+    want = oracle.quantize(oracle.normalize_embeddings(raw).astype(np.float32), "f16")
+    got = idx.reconstruct_n()
+    # device fp32 norm vs numpy's: at most one fp16 ulp apart
+    np.testing.assert_allclose(got, want, atol=2 ** -11, rtol=0)
+    assert (got != want).mean() < 0.01
+    idx.close()
+
+
+def test_torch_tensor_interface_and_id_offset(torch_mod):
+    torch = torch_mod
+    corpus = make_corpus(2000, 128, dtype="f16")
+    queries = make_corpus(16, 128, seed=8, dtype="f16")
+    idx = _index(128, "f16")
+    idx.add(torch.from_numpy(corpus).cuda().half())
+    idx.set_id_offset(1_000_000_000_000)
+    D, I = idx.search(torch.from_numpy(queries).cuda().half(), 25)
+    assert D.is_cuda and I.dtype == torch.int64
+    check_topk(D.cpu().numpy(), I.cpu().numpy(), corpus, queries, 25, id_offset=1_000_000_000_000)
+    idx.close()
+
+
+def test_merge_topk_matches_oracle(torch_mod):
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    R, B, k = 8, 64, 1000
+    s = np.sort(rng.standard_normal((R, B, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ids = np.stack([np.sort(rng.choice(10**6, size=(B, k)), axis=1) + r * 10**6 for r in range(R)]).astype(np.int64)
+    s[1, :, 10:20] = s[0, :, 10:20]                       # cross-list exact score ties
+    s[1] = np.sort(s[1], axis=1)[:, ::-1]
+    s[7, 3, 500:] = -3.4028234663852886e38                # a short list: padded tail
+    ids[7, 3, 500:] = -1
+    from tristage_rag_amd.index import merge_topk
+    D, I = merge_topk(torch.from_numpy(s).cuda(), torch.from_numpy(ids).cuda())
+    D0, I0 = oracle.merge_topk(s, ids, k)
+    assert np.array_equal(I.cpu().numpy(), I0)
+    np.testing.assert_array_equal(D.cpu().numpy(), D0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["maxsim", "colbert"])
+def test_maxsim_kernel_matches_oracle(torch_mod, dtype, mode):
+    torch = torch_mod
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    rng = np.random.default_rng(21)
+    H, Lq = 96, 19
+    lens = [1, 31, 32, 33, 64, 100, 192, 7, 0, 150]
+    q = oracle.quantize(rng.standard_normal((Lq, H)).astype(np.float32), dtype)
+    docs = [oracle.quantize(rng.standard_normal((L, H)).astype(np.float32), dtype) for L in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    from tristage_rag_amd.index import maxsim
+    out = maxsim(torch.from_numpy(q).cuda().to(tdt), torch.from_numpy(np.concatenate(docs, 0)).cuda().to(tdt),
+                 torch.from_numpy(off).cuda(), mode=mode).cpu().numpy()
+    want = oracle.maxsim_scores(q, docs, mode)
+    np.testing.assert_allclose(out, want, atol=2e-6, rtol=0)   # bar is 1e-3; f32 MFMA gets ~1e-7
+    assert out[8] == 0.0
+
+
+def test_maxsim_kernel_on_reference_golden_cases(torch_mod):
+    torch = torch_mod
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat.json")))
+    from tristage_rag_amd.index import maxsim
+    for case in kat["maxsim"]:
+        q = torch.tensor(case["q"], dtype=torch.float32).cuda()
+        d = torch.tensor(case["d"], dtype=torch.float32).cuda()
+        off = torch.tensor([0, d.shape[0]], dtype=torch.int32).cuda()
+        for mode in ("maxsim", "colbert"):
+            got = float(maxsim(q, d, off, mode=mode)[0])
+            assert got == pytest.approx(case[mode], abs=2e-6)      # reference: torch fp32 on CPU
+
+
+def test_long_query_and_odd_hidden_size(torch_mod):
+    torch = torch_mod
+    rng = np.random.default_rng(2)
+    H, Lq = 50, 192
+    q = rng.standard_normal((Lq, H)).astype(np.float32)
+    docs = [rng.standard_normal((L, H)).astype(np.float32) for L in (5, 70)]
+    off = np.array([0, 5, 75], np.int32)
+    from tristage_rag_amd.index import maxsim
+    out = maxsim(torch.from_numpy(q).cuda(), torch.from_numpy(np.concatenate(docs, 0)).cuda(),
+                 torch.from_numpy(off).cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, oracle.maxsim_scores(q, docs), atol=2e-6, rtol=0)

@@ -1,0 +1,96 @@
+"""ctypes binding of libtristage.so (the C ABI declared in include/tristage.h).
+
+The HIP library IS the product path: if it is missing or cannot be loaded this
+module raises — there is no CPU or PyTorch fallback behind it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtristage.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+TS_OK = 0
+TS_ERR_INVALID, TS_ERR_HIP, TS_ERR_OOM, TS_ERR_EMPTY, TS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+TS_F32, TS_F16, TS_BF16 = 0, 1, 2
+TS_METRIC_INNER_PRODUCT = 0
+TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE = 1, 2, 4
+
+# name -> (restype, argtypes); mirrors include/tristage.h one to one
+SIGNATURES = {
+    "ts_index_create": (c_int32, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "ts_index_destroy": (c_int32, [c_void_p]),
+    "ts_index_reset": (c_int32, [c_void_p]),
+    "ts_index_reserve": (c_int32, [c_void_p, c_int64]),
+    "ts_index_add": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_uint32, c_void_p]),
+    "ts_index_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
+                                  c_void_p, c_uint32, c_void_p]),
+    "ts_index_ntotal": (c_int64, [c_void_p]),
+    "ts_index_dim": (c_int32, [c_void_p]),
+    "ts_index_dtype": (c_int32, [c_void_p]),
+    "ts_index_set_id_offset": (c_int32, [c_void_p, c_int64]),
+    "ts_index_reconstruct": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_uint32, c_void_p]),
+    "ts_index_last_search_info": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "ts_index_set_profiling": (c_int32, [c_void_p, c_int32]),
+    "ts_index_get_timings": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
+    "ts_merge_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                c_int32, c_void_p]),
+    "ts_maxsim": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                            c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_last_error": (c_char_p, []),
+    "ts_abi_version": (c_int32, []),
+}
+
+_lib = None
+
+
+class TriStageNativeError(RuntimeError):
+    """A libtristage.so call failed (message from ts_last_error())."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libtristage error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def build(force: bool = False) -> str:
+    """Compile libtristage.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.run(["make", "-C", CSRC_DIR], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.STDOUT)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the library and bind every symbol of the header. Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.ts_abi_version() != 1:
+        raise ImportError("libtristage.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().ts_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(code: int) -> None:
+    if code != TS_OK:
+        raise TriStageNativeError(code, last_error())

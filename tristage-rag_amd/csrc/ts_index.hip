@@ -1,0 +1,586 @@
+// libtristage.so — index handle, search orchestration and the C ABI
+// (include/tristage.h).  The handle plays the role of the FAISS index object
+// the reference keeps in Stage1Retriever.faiss_index
+// (reference src/stage1_retriever.py:126, 256-283, 313, 380).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "ts_common.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void ts_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ts_last_error(void) { return g_err; }
+extern "C" int ts_abi_version(void) { return TS_ABI_VERSION; }
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+int ensure(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return TS_OK;
+  if (b.p) {
+    TS_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  // round up so slowly growing requests do not reallocate every time
+  size_t want = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    ts_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    return TS_ERR_OOM;
+  }
+  b.bytes = want;
+  return TS_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+}  // namespace
+#define TS_NPHASE 8
+namespace {
+// tuning constants of the filter path (DESIGN.md "threshold sampling")
+constexpr int64_t kMinFilterRows = 32768;   // below this the dense path is used
+constexpr int kMaxFilterK = 2048;
+constexpr uint32_t kCandCap = 16384;        // candidate slots per query
+constexpr int64_t kMinSampleRows = 8192;
+constexpr int64_t kSampleDiv = 128;         // sample >= N/128 rows
+constexpr uint32_t kMinSampleRank = 24;
+constexpr uint32_t kOversample = 4;         // expected candidates ~ 4k per query
+constexpr int64_t kDenseChunkRows = 1 << 20;
+
+}  // namespace
+
+struct ts_index {
+  int device = 0;
+  int num_cus = 256;
+  TsLayout L{};
+  int64_t ntotal = 0;
+  int64_t cap_blocks = 0;
+  uint4* corpus = nullptr;
+  int64_t id_offset = 0;
+  int64_t info[4] = {0, 0, 0, 0};
+  // workspace (grown on demand, never inside a steady-state search)
+  DevBuf qimg, small, cand_score, cand_id, sample, dense, list_score, list_id;
+  DevBuf stage, den, qstage, out_s, out_i;
+  uint32_t* host_status = nullptr;  // pinned
+  // optional per-phase timing with HIP events on the caller's stream
+  bool profiling = false;
+  hipEvent_t ev[TS_NPHASE + 1] = {};
+  int ev_phase[TS_NPHASE + 1] = {};
+  int nev = 0;
+  double phase_ms[TS_NPHASE] = {};
+  int64_t phase_cnt[TS_NPHASE] = {};
+  float* tau() { return (float*)small.p; }
+  uint32_t* cand_cnt() { return (uint32_t*)small.p + 64; }
+  uint32_t* status() { return (uint32_t*)small.p + 128; }
+};
+
+// profiling: mark(h, phase, s) records an event; the time between two marks is
+// charged to the phase of the FIRST mark.  Collected after the search's sync.
+static void prof_mark(ts_index* h, int phase, hipStream_t s) {
+  if (!h->profiling || h->nev > TS_NPHASE) return;
+  if (hipEventRecord(h->ev[h->nev], s) != hipSuccess) return;
+  h->ev_phase[h->nev] = phase;
+  ++h->nev;
+}
+static void prof_collect(ts_index* h) {
+  if (!h->profiling) return;
+  for (int i = 0; i + 1 < h->nev; ++i) {
+    float ms = 0.f;
+    const int ph = h->ev_phase[i];
+    if (ph >= 0 && ph < TS_NPHASE && hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) {
+      h->phase_ms[ph] += ms;
+      h->phase_cnt[ph] += 1;
+    }
+  }
+  h->nev = 0;
+}
+
+static int grow_corpus(ts_index* h, int64_t need_blocks, bool exact, hipStream_t s) {
+  if (need_blocks <= h->cap_blocks) return TS_OK;
+  int64_t new_cap = need_blocks;
+  if (!exact && h->cap_blocks > 0) new_cap = std::max(need_blocks, h->cap_blocks + h->cap_blocks / 2);
+  const size_t bb = ts_block_bytes(h->L);
+  void* np = nullptr;
+  hipError_t e = hipMalloc(&np, (size_t)new_cap * bb);
+  if (e != hipSuccess) {
+    ts_set_error("cannot allocate %zu bytes for the corpus: %s", (size_t)new_cap * bb,
+                 hipGetErrorString(e));
+    return TS_ERR_OOM;
+  }
+  const int64_t used_blocks = (h->ntotal + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  if (used_blocks > 0)
+    TS_HIP(hipMemcpyAsync(np, h->corpus, (size_t)used_blocks * bb, hipMemcpyDeviceToDevice, s));
+  TS_HIP(hipMemsetAsync((char*)np + (size_t)used_blocks * bb, 0,
+                        (size_t)(new_cap - used_blocks) * bb, s));
+  TS_HIP(hipStreamSynchronize(s));
+  if (h->corpus) TS_HIP(hipFree(h->corpus));
+  h->corpus = (uint4*)np;
+  h->cap_blocks = new_cap;
+  return TS_OK;
+}
+
+extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metric,
+                               int32_t device, ts_index** out) {
+  if (!out) { ts_set_error("out is null"); return TS_ERR_INVALID; }
+  *out = nullptr;
+  if (dim <= 0 || dim > 65536) { ts_set_error("bad dim %d", dim); return TS_ERR_INVALID; }
+  if (storage_dtype != TS_F32 && storage_dtype != TS_F16 && storage_dtype != TS_BF16) {
+    ts_set_error("bad storage dtype %d", storage_dtype);
+    return TS_ERR_INVALID;
+  }
+  if (metric != TS_METRIC_INNER_PRODUCT) {
+    ts_set_error("only the inner-product metric is supported (reference uses IndexFlatIP)");
+    return TS_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  TS_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    ts_set_error("device %d not present (%d HIP devices)", device, ndev);
+    return TS_ERR_INVALID;
+  }
+  TsLayout L = ts_make_layout(dim, storage_dtype);
+  if ((size_t)L.kg * 1024 > 160 * 1024) {
+    ts_set_error("dim %d with dtype %d needs %d KiB of LDS for 32 queries (max 160)", dim,
+                 storage_dtype, L.kg);
+    return TS_ERR_UNSUPPORTED;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  ts_index* h = new (std::nothrow) ts_index();
+  if (!h) { ts_set_error("out of host memory"); return TS_ERR_OOM; }
+  h->device = device;
+  h->L = L;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    h->num_cus = prop.multiProcessorCount;
+  int st = ensure(h->small, 4096);
+  if (st == TS_OK) st = ensure(h->qimg, (size_t)L.kg * 2 * 1024);
+  if (st == TS_OK && hipHostMalloc((void**)&h->host_status, 512, hipHostMallocDefault) != hipSuccess) {
+    ts_set_error("hipHostMalloc failed");
+    st = TS_ERR_HIP;
+  }
+  if (st != TS_OK) {
+    ts_index_destroy(h);
+    return st;
+  }
+  *out = h;
+  return TS_OK;
+}
+
+extern "C" int ts_index_destroy(ts_index* h) {
+  if (!h) return TS_OK;
+  DeviceGuard g(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->corpus) (void)hipFree(h->corpus);
+  DevBuf* bufs[] = {&h->qimg, &h->small, &h->cand_score, &h->cand_id, &h->sample,
+                    &h->dense, &h->list_score, &h->list_id, &h->stage, &h->den,
+                    &h->qstage, &h->out_s, &h->out_i};
+  for (DevBuf* b : bufs) release(*b);
+  if (h->host_status) (void)hipHostFree(h->host_status);
+  for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete h;
+  return TS_OK;
+}
+
+extern "C" int ts_index_reset(ts_index* h) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  h->ntotal = 0;
+  return TS_OK;
+}
+
+extern "C" int ts_index_reserve(ts_index* h, int64_t nrows) {
+  if (!h || nrows < 0) { ts_set_error("bad arguments"); return TS_ERR_INVALID; }
+  if (nrows >= (1LL << 31)) { ts_set_error("at most 2^31-1 rows per index"); return TS_ERR_UNSUPPORTED; }
+  DeviceGuard g(h->device);
+  return grow_corpus(h, (nrows + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK, true, nullptr);
+}
+
+extern "C" int64_t ts_index_ntotal(const ts_index* h) { return h ? h->ntotal : -1; }
+extern "C" int32_t ts_index_dim(const ts_index* h) { return h ? h->L.dim : -1; }
+extern "C" int32_t ts_index_dtype(const ts_index* h) { return h ? h->L.dtype : -1; }
+
+extern "C" int ts_index_set_id_offset(ts_index* h, int64_t offset) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  h->id_offset = offset;
+  return TS_OK;
+}
+
+extern "C" int ts_index_last_search_info(const ts_index* h, int64_t info[4]) {
+  if (!h || !info) { ts_set_error("bad arguments"); return TS_ERR_INVALID; }
+  for (int i = 0; i < 4; ++i) info[i] = h->info[i];
+  return TS_OK;
+}
+
+static size_t dtype_size(int dt) { return dt == TS_F32 ? 4 : 2; }
+static bool dtype_ok(int dt) { return dt == TS_F32 || dt == TS_F16 || dt == TS_BF16; }
+
+extern "C" int ts_index_add(ts_index* h, const void* rows, int64_t n, int32_t rows_dtype,
+                            uint32_t flags, void* stream) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  if (n == 0) return TS_OK;
+  if (!rows || n < 0 || !dtype_ok(rows_dtype)) { ts_set_error("bad arguments to add"); return TS_ERR_INVALID; }
+  if (h->ntotal + n >= (1LL << 31)) { ts_set_error("at most 2^31-1 rows per index"); return TS_ERR_UNSUPPORTED; }
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t need_blocks = (h->ntotal + n + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  TS_CHECK(grow_corpus(h, need_blocks, false, s));
+  const bool norm = (flags & TS_FLAG_NORMALIZE) != 0;
+  const size_t row_bytes = (size_t)h->L.dim * dtype_size(rows_dtype);
+  if (flags & TS_FLAG_HOST_PTR) {
+    // chunked upload through a device staging buffer
+    int64_t chunk = std::max<int64_t>(1, (int64_t)((64u << 20) / row_bytes));
+    chunk = std::min(chunk, n);
+    TS_CHECK(ensure(h->stage, (size_t)chunk * row_bytes));
+    if (norm) TS_CHECK(ensure(h->den, (size_t)chunk * 4));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t c = std::min(chunk, n - r0);
+      TS_HIP(hipMemcpyAsync(h->stage.p, (const char*)rows + (size_t)r0 * row_bytes,
+                            (size_t)c * row_bytes, hipMemcpyHostToDevice, s));
+      TS_CHECK(ts_launch_relayout(h->L, h->stage.p, rows_dtype, c, h->ntotal + r0, h->corpus,
+                                  norm, (float*)h->den.p, s));
+      // the staging buffer is reused by the next chunk
+      TS_HIP(hipStreamSynchronize(s));
+    }
+  } else {
+    if (norm) TS_CHECK(ensure(h->den, (size_t)n * 4));
+    TS_CHECK(ts_launch_relayout(h->L, rows, rows_dtype, n, h->ntotal, h->corpus, norm,
+                                (float*)h->den.p, s));
+    TS_HIP(hipStreamSynchronize(s));
+  }
+  h->ntotal += n;
+  return TS_OK;
+}
+
+extern "C" int ts_index_reconstruct(ts_index* h, int64_t row0, int64_t n, float* out,
+                                    uint32_t flags, void* stream) {
+  if (!h || !out || row0 < 0 || n < 0 || row0 + n > h->ntotal) {
+    ts_set_error("bad arguments to reconstruct");
+    return TS_ERR_INVALID;
+  }
+  if (n == 0) return TS_OK;
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & TS_FLAG_HOST_PTR) {
+    const size_t row_bytes = (size_t)h->L.dim * 4;
+    int64_t chunk = std::max<int64_t>(1, (int64_t)((64u << 20) / row_bytes));
+    chunk = std::min(chunk, n);
+    TS_CHECK(ensure(h->stage, (size_t)chunk * row_bytes));
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+      const int64_t c = std::min(chunk, n - r0);
+      TS_CHECK(ts_launch_reconstruct(h->L, h->corpus, row0 + r0, c, (float*)h->stage.p, s));
+      TS_HIP(hipMemcpyAsync((char*)out + (size_t)r0 * row_bytes, h->stage.p,
+                            (size_t)c * row_bytes, hipMemcpyDeviceToHost, s));
+      TS_HIP(hipStreamSynchronize(s));
+    }
+  } else {
+    TS_CHECK(ts_launch_reconstruct(h->L, h->corpus, row0, n, out, s));
+    TS_HIP(hipStreamSynchronize(s));
+  }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ search
+static int dense_path(ts_index* h, int nq, int qh, int k, float* out_s, int64_t* out_i,
+                      hipStream_t s) {
+  const int64_t N = h->ntotal;
+  const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  const int64_t chunk_rows = std::min<int64_t>(kDenseChunkRows, nblk * TS_ROWS_PER_BLOCK);
+  const int64_t nch = (nblk * TS_ROWS_PER_BLOCK + chunk_rows - 1) / chunk_rows;
+  TS_CHECK(ensure(h->dense, (size_t)nq * chunk_rows * 4));
+  if (nch > 1) {
+    TS_CHECK(ensure(h->list_score, (size_t)nq * nch * k * 4));
+    TS_CHECK(ensure(h->list_id, (size_t)nq * nch * k * 4));
+  }
+  for (int64_t c = 0; c < nch; ++c) {
+    const int64_t row0 = c * chunk_rows;
+    const int64_t rows = std::min(chunk_rows, N - row0);
+    ScanParams sp{};
+    sp.corpus = h->corpus;
+    sp.qimg = (const uint4*)h->qimg.p;
+    sp.kg = h->L.kg;
+    sp.nq = nq;
+    sp.nwork = (rows + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+    sp.blk0 = row0 / TS_ROWS_PER_BLOCK;
+    sp.blk_stride = 1;
+    sp.ntotal = N;
+    sp.dense = (float*)h->dense.p;
+    sp.dense_ld = chunk_rows;
+    TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
+    SelParams p{};
+    p.mode = SEL_DENSE;
+    p.scores = (const float*)h->dense.p;
+    p.stride = chunk_rows;
+    p.n = (uint32_t)rows;
+    p.id_base = (int32_t)row0;
+    p.k = k;
+    if (nch == 1) {
+      p.out_scores = out_s;
+      p.out_ids64 = out_i;
+      p.out_stride = k;
+      p.id_offset = h->id_offset;
+    } else {
+      p.out_scores = (float*)h->list_score.p + c * k;
+      p.out_ids32 = (int32_t*)h->list_id.p + c * k;
+      p.out_stride = nch * k;
+    }
+    TS_CHECK(ts_launch_select(p, nq, s));
+  }
+  if (nch > 1) {
+    SelParams p{};
+    p.mode = SEL_PAIRS32;
+    p.scores = (const float*)h->list_score.p;
+    p.ids32 = (const int32_t*)h->list_id.p;
+    p.stride = nch * k;
+    p.n = (uint32_t)(nch * k);
+    p.k = k;
+    p.out_scores = out_s;
+    p.out_ids64 = out_i;
+    p.out_stride = k;
+    p.id_offset = h->id_offset;
+    TS_CHECK(ts_launch_select(p, nq, s));
+  }
+  return TS_OK;
+}
+
+// one pass of <= 32*qh queries (device pointers)
+static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, float* out_s,
+                       int64_t* out_i, uint32_t flags, hipStream_t s) {
+  const int64_t N = h->ntotal;
+  const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  const int qh = nq > 32 ? 2 : 1;
+  const bool filter = !(flags & TS_FLAG_NO_FILTER) && k <= kMaxFilterK && N >= kMinFilterRows &&
+                      N >= 32 * (int64_t)k;
+  h->nev = 0;
+  prof_mark(h, 0, s);
+  TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)h->qimg.p, h->cand_cnt(),
+                           h->status(), s));
+  if (!filter) {
+    h->info[0] = 0; h->info[1] = 0; h->info[2] = 0; h->info[3] = 0;
+    prof_mark(h, 5, s);
+    TS_CHECK(dense_path(h, nq, qh, k, out_s, out_i, s));
+    prof_mark(h, -1, s);
+    TS_HIP(hipStreamSynchronize(s));
+    prof_collect(h);
+    return TS_OK;
+  }
+  // ---- filter path: sample -> thresholds -> fused scan+filter -> select
+  int64_t nsb = std::max(kMinSampleRows, N / kSampleDiv) / TS_ROWS_PER_BLOCK;
+  nsb = std::min(nsb, nblk);
+  const int64_t sstride = nblk / nsb;
+  const int64_t S = nsb * TS_ROWS_PER_BLOCK;
+  uint32_t m = (uint32_t)((kOversample * (int64_t)k * S + N - 1) / N);
+  m = std::max(m, kMinSampleRank);
+  TS_CHECK(ensure(h->sample, (size_t)nq * S * 4));
+  TS_CHECK(ensure(h->cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
+  TS_CHECK(ensure(h->cand_id, (size_t)TS_MAX_Q * kCandCap * 4));
+
+  ScanParams sp{};
+  sp.corpus = h->corpus;
+  sp.qimg = (const uint4*)h->qimg.p;
+  sp.kg = h->L.kg;
+  sp.nq = nq;
+  sp.ntotal = N;
+  // (1) dense scores of a strided sample of row blocks
+  sp.nwork = nsb;
+  sp.blk0 = 0;
+  sp.blk_stride = sstride;
+  sp.dense = (float*)h->sample.p;
+  sp.dense_ld = S;
+  prof_mark(h, 1, s);
+  TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
+  prof_mark(h, 2, s);
+  // (2) per-query threshold = ~m-th best sample score
+  TS_CHECK(ts_launch_tau((const float*)h->sample.p, S, (uint32_t)S, m, nq, h->tau(), s));
+  // (3) the full scan; only scores >= tau leave the registers
+  sp.nwork = nblk;
+  sp.blk_stride = 1;
+  sp.dense = nullptr;
+  sp.tau = h->tau();
+  sp.cand_cnt = h->cand_cnt();
+  sp.cand_score = (float*)h->cand_score.p;
+  sp.cand_id = (int32_t*)h->cand_id.p;
+  sp.cand_cap = kCandCap;
+  prof_mark(h, 3, s);
+  TS_CHECK(ts_launch_scan(h->L, SCAN_FILTER, qh, sp, h->num_cus, s));
+  prof_mark(h, 4, s);
+  // (4) exact top-k of the candidates; verifies that >= k of them exist
+  SelParams p{};
+  p.mode = SEL_PAIRS32;
+  p.scores = (const float*)h->cand_score.p;
+  p.ids32 = (const int32_t*)h->cand_id.p;
+  p.stride = kCandCap;
+  p.n_per_q = h->cand_cnt();
+  p.n_cap = kCandCap;
+  p.need = (uint32_t)std::min<int64_t>(k, N);
+  p.k = k;
+  p.out_scores = out_s;
+  p.out_ids64 = out_i;
+  p.out_stride = k;
+  p.id_offset = h->id_offset;
+  p.status = h->status();
+  TS_CHECK(ts_launch_select(p, nq, s));
+  prof_mark(h, -1, s);
+  // the 64 candidate counts and the status word come back together
+  TS_HIP(hipMemcpyAsync(h->host_status, h->cand_cnt(), 65 * 4, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipStreamSynchronize(s));
+  prof_collect(h);
+  uint32_t maxc = 0;
+  for (int i = 0; i < nq; ++i) maxc = std::max(maxc, h->host_status[i]);
+  h->info[0] = 1; h->info[1] = maxc; h->info[2] = S; h->info[3] = m;
+  if (h->host_status[64] != 0) {
+    // a threshold was too high (fewer than k survivors) or too low (candidate
+    // list overflowed, e.g. massive score ties): redo this pass exactly.
+    h->info[0] = 2;
+    prof_mark(h, 5, s);
+    TS_CHECK(dense_path(h, nq, qh, k, out_s, out_i, s));
+    prof_mark(h, -1, s);
+    TS_HIP(hipStreamSynchronize(s));
+    prof_collect(h);
+  }
+  return TS_OK;
+}
+
+extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int32_t q_dtype,
+                               int32_t k, float* out_scores, int64_t* out_ids, uint32_t flags,
+                               void* stream) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  if (nq == 0) return TS_OK;
+  if (!queries || !out_scores || !out_ids || nq < 0 || k <= 0 || !dtype_ok(q_dtype)) {
+    ts_set_error("bad arguments to search");
+    return TS_ERR_INVALID;
+  }
+  if (h->ntotal == 0) {
+    ts_set_error("No documents indexed. Call add_documents() first.");
+    return TS_ERR_EMPTY;
+  }
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int qp = ((size_t)h->L.kg * 2 * 1024 <= 160 * 1024) ? 64 : 32;  // queries per pass
+  const size_t qrow = (size_t)h->L.dim * dtype_size(q_dtype);
+  const void* dq = queries;
+  float* ds = out_scores;
+  int64_t* di = out_ids;
+  const bool host = (flags & TS_FLAG_HOST_PTR) != 0;
+  if (host) {
+    TS_CHECK(ensure(h->qstage, (size_t)nq * qrow));
+    TS_CHECK(ensure(h->out_s, (size_t)nq * k * 4));
+    TS_CHECK(ensure(h->out_i, (size_t)nq * k * 8));
+    TS_HIP(hipMemcpyAsync(h->qstage.p, queries, (size_t)nq * qrow, hipMemcpyHostToDevice, s));
+    dq = h->qstage.p;
+    ds = (float*)h->out_s.p;
+    di = (int64_t*)h->out_i.p;
+  }
+  for (int q0 = 0; q0 < nq; q0 += qp) {
+    const int c = std::min(qp, nq - q0);
+    TS_CHECK(search_pass(h, (const char*)dq + (size_t)q0 * qrow, c, q_dtype, k,
+                         ds + (size_t)q0 * k, di + (size_t)q0 * k, flags, s));
+  }
+  if (host) {
+    TS_HIP(hipMemcpyAsync(out_scores, ds, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+    TS_HIP(hipMemcpyAsync(out_ids, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    TS_HIP(hipStreamSynchronize(s));
+  }
+  return TS_OK;
+}
+
+extern "C" int ts_index_set_profiling(ts_index* h, int32_t on) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  DeviceGuard g(h->device);
+  if (on && !h->ev[0]) {
+    for (hipEvent_t& e : h->ev) TS_HIP(hipEventCreate(&e));
+  }
+  h->profiling = on != 0;
+  return TS_OK;
+}
+
+extern "C" int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t reset) {
+  if (!h || !ms || !counts) { ts_set_error("bad arguments"); return TS_ERR_INVALID; }
+  for (int i = 0; i < TS_NPHASE; ++i) {
+    ms[i] = h->phase_ms[i];
+    counts[i] = h->phase_cnt[i];
+    if (reset) { h->phase_ms[i] = 0.0; h->phase_cnt[i] = 0; }
+  }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ merge
+extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
+                             int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
+                             int32_t device, void* stream) {
+  if (!scores || !ids || !out_scores || !out_ids || nlists <= 0 || nq < 0 || k <= 0) {
+    ts_set_error("bad arguments to merge");
+    return TS_ERR_INVALID;
+  }
+  if (nq == 0) return TS_OK;
+  if ((int64_t)nlists * k > TS_SEL_LDS_KEYS) {
+    ts_set_error("merge: nlists*k = %lld exceeds %d", (long long)nlists * k, TS_SEL_LDS_KEYS);
+    return TS_ERR_UNSUPPORTED;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  SelParams p{};
+  p.mode = SEL_MERGE64;
+  p.scores = scores;
+  p.ids64 = ids;
+  p.stride = k;                       // query q of list 0 starts at q*k
+  p.seg_len = (uint32_t)k;
+  p.seg_stride = (int64_t)nq * k;     // next list
+  p.n = (uint32_t)(nlists * k);
+  p.k = k;
+  p.out_scores = out_scores;
+  p.out_ids64 = out_ids;
+  p.out_stride = k;
+  TS_CHECK(ts_launch_select(p, nq, (hipStream_t)stream));
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ maxsim
+extern "C" int ts_maxsim(const void* q, int32_t Lq, const void* docs, const int32_t* doc_off,
+                         int32_t n_docs, int32_t H, int32_t dtype, int32_t mode, float* out,
+                         int32_t device, void* stream) {
+  if (n_docs == 0) return TS_OK;
+  if (!q || !docs || !doc_off || !out || Lq < 0 || n_docs < 0 || H <= 0 || !dtype_ok(dtype) ||
+      (mode != 0 && mode != 1)) {
+    ts_set_error("bad arguments to maxsim");
+    return TS_ERR_INVALID;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  return ts_launch_maxsim(q, Lq, docs, doc_off, n_docs, H, dtype, mode, out, (hipStream_t)stream);
+}

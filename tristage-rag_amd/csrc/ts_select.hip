@@ -1,0 +1,309 @@
+// Exact top-k selection for gfx950: the part of faiss_index.search
+// (reference src/stage1_retriever.py:380) that turns scores into the k best
+// (score desc, id asc) — plus the threshold estimate that lets the scan kernel
+// drop >99.9 % of the scores on the fly, and the merge of per-shard lists.
+//
+// One 1024-thread workgroup per query.  Everything is ordered by a 64-bit key
+//     key = orderable(score) << 32 | (0xFFFFFFFF - tiebreak)
+// so "larger key" == "better" and keys are unique (tiebreak = row id, or the
+// position in the concatenated lists for the int64-id merge, where exact
+// score ties are then resolved by comparing the real ids).
+//   phase 1 (only when the entries do not fit LDS): MSB-first 8-bit radix
+//            select over the keys in global memory -> key of the k-th best
+//   phase 2: compact the survivors (key >= T) into LDS
+//   phase 3: bitonic sort in LDS, write the first k.
+#include "ts_common.h"
+
+#define SEL_THREADS 1024
+#define NEG_MAX (-3.402823466e38f)
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  if (f != f) return 0u;  // NaN ranks last
+  f = f + 0.0f;           // -0 -> +0 so equal scores have equal keys
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, u);
+}
+
+// entry e of a query lives at qbase + e, or — when the entries are the
+// concatenation of `seg_len`-long lists that are `seg_stride` apart (the
+// [nlists, nq, k] layout an all-gather produces) — at the address below
+__device__ __forceinline__ int64_t entry_addr(const SelParams& p, int64_t qbase, uint32_t e) {
+  if (p.seg_len == 0) return qbase + e;
+  return qbase + (int64_t)(e / p.seg_len) * p.seg_stride + (e % p.seg_len);
+}
+
+template <int MODE>
+__device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase,
+                                             uint32_t i) {
+  const int64_t a = entry_addr(p, qbase, i);
+  const float s = p.scores[a];
+  uint32_t tb;
+  if constexpr (MODE == SEL_DENSE) {
+    tb = i + (uint32_t)p.id_base;
+  } else if constexpr (MODE == SEL_PAIRS32) {
+    const int32_t id = p.ids32[a];
+    if (id < 0) return 0ull;  // padding entry of a short list
+    tb = (uint32_t)id;
+  } else {
+    if (p.ids64[a] < 0) return 0ull;
+    tb = i;
+  }
+  return ((uint64_t)f2key(s) << 32) | (uint64_t)(0xFFFFFFFFu - tb);
+}
+
+template <int MODE>
+__device__ __forceinline__ bool key_before(const SelParams& p, int64_t qbase,
+                                           uint64_t a, uint64_t b) {
+  // true when a must come before b in the output (a is "better")
+  if constexpr (MODE == SEL_MERGE64) {
+    const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
+    if (sa != sb) return sa > sb;
+    if (a == 0ull || b == 0ull) return a > b;
+    const int64_t ia = p.ids64[entry_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)a)];
+    const int64_t ib = p.ids64[entry_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)b)];
+    return ia < ib;
+  } else {
+    return a > b;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32_t lds_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)lds_keys * 8);  // [256]
+  uint32_t* sh = hist + 256;  // [8] scratch
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t qbase = (int64_t)q * p.stride;
+
+  uint32_t n = p.n;
+  if (p.n_per_q) {
+    const uint32_t c = p.n_per_q[q];
+    n = c < p.n_cap ? c : p.n_cap;
+    if (tid == 0 && p.status) {
+      uint32_t st = 0;
+      if (c > p.n_cap) st |= TS_STATUS_OVERFLOW;
+      if (c < p.need) st |= TS_STATUS_SHORT;
+      if (st) atomicOr(p.status, st);
+    }
+  }
+  const uint32_t kk = (uint32_t)p.k < n ? (uint32_t)p.k : n;
+
+  // ---- phase 1: radix select of the kk-th largest key (only if n > LDS room)
+  uint64_t T = 0ull;
+  uint32_t count;  // survivors
+  if (n > lds_keys) {
+    uint64_t prefix = 0ull;
+    int bits_done = 0;
+    uint32_t krem = kk;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < n; base += 4 * SEL_THREADS) {  // wave-uniform trip count
+        uint64_t kx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = base + u * SEL_THREADS + tid;
+          kx[u] = (i < n) ? load_key<MODE>(p, qbase, i) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = base + u * SEL_THREADS + tid;
+          const bool in = (i < n) && (bits_done == 0 || (kx[u] >> (64 - bits_done)) == prefix);
+          const uint32_t digit = (uint32_t)(kx[u] >> shift) & 0xFFu;
+          // wave-uniform fast path: concentrated scores put whole waves in one bin
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+          if (m) {
+            const int src = __builtin_ctzll(m);
+            const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
+            if (same == m) {
+              if ((tid & 63) == src) atomicAdd(&hist[d0], (uint32_t)__builtin_popcountll(m));
+            } else if (in) {
+              atomicAdd(&hist[digit], 1u);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0;
+        int d = 255;
+        for (; d > 0; --d) {
+          const uint32_t c = hist[d];
+          if (cum + c >= krem) break;
+          cum += c;
+        }
+        sh[0] = (uint32_t)d;
+        sh[1] = krem - cum;
+        sh[2] = (hist[d] == krem - cum) ? 1u : 0u;
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | (uint64_t)sh[0];
+      krem = sh[1];
+      bits_done += 8;
+      const bool done = sh[2] != 0;
+      __syncthreads();
+      if (done) break;
+    }
+    T = (bits_done == 64) ? prefix : (prefix << (64 - bits_done));
+    // ---- phase 2: compact survivors
+    if (tid == 0) sh[3] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+      const uint64_t key = load_key<MODE>(p, qbase, i);
+      if (key >= T && key != 0ull) {
+        const uint32_t pos = atomicAdd(&sh[3], 1u);
+        if (pos < lds_keys) keys[pos] = key;
+      }
+    }
+    __syncthreads();
+    count = sh[3] < lds_keys ? sh[3] : lds_keys;
+  } else {
+    for (uint32_t i = tid; i < n; i += SEL_THREADS) keys[i] = load_key<MODE>(p, qbase, i);
+    count = n;
+  }
+
+  // ---- phase 3: bitonic sort (descending by key_before) over P >= count
+  uint32_t P = 2;
+  while (P < count) P <<= 1;
+  for (uint32_t i = count + tid; i < P; i += SEL_THREADS) keys[i] = 0ull;
+  __syncthreads();
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+        const uint32_t i = 2 * t - (t & (stride - 1));
+        const uint32_t j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint64_t a = keys[i], b = keys[j];
+        const bool swap = desc ? key_before<MODE>(p, qbase, b, a)
+                               : key_before<MODE>(p, qbase, a, b);
+        if (swap) { keys[i] = b; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- output
+  float* os = p.out_scores + (int64_t)q * p.out_stride;
+  for (uint32_t i = tid; i < (uint32_t)p.k; i += SEL_THREADS) {
+    const uint64_t key = (i < count) ? keys[i] : 0ull;
+    float s = NEG_MAX;
+    int64_t id = -1;
+    if (i < kk && key != 0ull) {
+      s = key2f((uint32_t)(key >> 32));
+      const uint32_t tb = 0xFFFFFFFFu - (uint32_t)key;
+      if constexpr (MODE == SEL_MERGE64) id = p.ids64[entry_addr(p, qbase, tb)];
+      else id = (int64_t)tb;
+    }
+    os[i] = s;
+    if (p.out_ids64) p.out_ids64[(int64_t)q * p.out_stride + i] = (id < 0) ? -1 : (MODE == SEL_MERGE64 ? id : id + p.id_offset);
+    if (p.out_ids32) p.out_ids32[(int64_t)q * p.out_stride + i] = (int32_t)id;
+  }
+}
+
+template <int MODE>
+static int launch_select_t(const SelParams& p, int nq, hipStream_t stream) {
+  // LDS: enough 64-bit keys for the entries (or for k when radix-selecting)
+  uint32_t nmax = p.n_per_q ? p.n_cap : p.n;
+  uint32_t need = nmax;
+  if (need > TS_SEL_LDS_KEYS) need = TS_SEL_LDS_KEYS;
+  uint32_t lds_keys = 2;
+  while (lds_keys < need) lds_keys <<= 1;
+  if (nmax > TS_SEL_LDS_KEYS) {
+    // radix path: room for the k survivors, rounded up to a power of two
+    uint32_t kk = (uint32_t)p.k;
+    if (kk > TS_SEL_LDS_KEYS) {
+      ts_set_error("k=%d exceeds the supported maximum %d for %u entries", p.k,
+                   TS_SEL_LDS_KEYS, nmax);
+      return TS_ERR_UNSUPPORTED;
+    }
+    lds_keys = 2;
+    while (lds_keys < kk) lds_keys <<= 1;
+  }
+  const size_t lds = (size_t)lds_keys * 8 + 256 * 4 + 8 * 4;
+  auto kern = select_kernel<MODE>;
+  TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(SEL_THREADS), lds, stream, p, lds_keys);
+  TS_HIP(hipGetLastError());
+  return TS_OK;
+}
+
+int ts_launch_select(const SelParams& p, int nq, hipStream_t stream) {
+  if (nq <= 0 || p.k <= 0) return TS_OK;
+  switch (p.mode) {
+    case SEL_DENSE: return launch_select_t<SEL_DENSE>(p, nq, stream);
+    case SEL_PAIRS32: return launch_select_t<SEL_PAIRS32>(p, nq, stream);
+    case SEL_MERGE64: return launch_select_t<SEL_MERGE64>(p, nq, stream);
+  }
+  ts_set_error("bad select mode %d", p.mode);
+  return TS_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ tau
+// Per-query threshold from a dense sample: every thread keeps the 4 largest
+// keys of its strided share, the 4096 survivors are sorted in LDS and the
+// m-th is taken.  This is a lower bound of the exact m-th largest (it can only
+// miss large values when one thread sees more than four of them), which is the
+// safe direction: a lower threshold admits more candidates, never fewer.
+__global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, int64_t ld,
+                                                          uint32_t n, uint32_t m, int nq,
+                                                          float* tau) {
+  __shared__ uint32_t keys[4 * SEL_THREADS];
+  const int q = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (q >= nq) {
+    if (tid == 0) tau[q] = 3.402823466e38f;
+    return;
+  }
+  const float* s = sample + (int64_t)q * ld;
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+    uint32_t k = f2key(s[i]);
+    if (k > a3) {
+      if (k > a0) { a3 = a2; a2 = a1; a1 = a0; a0 = k; }
+      else if (k > a1) { a3 = a2; a2 = a1; a1 = k; }
+      else if (k > a2) { a3 = a2; a2 = k; }
+      else a3 = k;
+    }
+  }
+  keys[tid] = a0;
+  keys[SEL_THREADS + tid] = a1;
+  keys[2 * SEL_THREADS + tid] = a2;
+  keys[3 * SEL_THREADS + tid] = a3;
+  __syncthreads();
+  const uint32_t P = 4 * SEL_THREADS;
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+        const uint32_t i = 2 * t - (t & (stride - 1));
+        const uint32_t j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint32_t a = keys[i], b = keys[j];
+        if (desc ? (b > a) : (a > b)) { keys[i] = b; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    uint32_t idx = m ? m - 1 : 0;
+    if (idx >= P) idx = P - 1;
+    const uint32_t k = keys[idx];
+    tau[q] = (k == 0u) ? NEG_MAX : key2f(k);
+  }
+}
+
+int ts_launch_tau(const float* sample, int64_t ld, uint32_t n, uint32_t m, int nq,
+                  float* tau, hipStream_t stream) {
+  hipLaunchKernelGGL(tau_kernel, dim3(TS_MAX_Q), dim3(SEL_THREADS), 0, stream, sample,
+                     ld, n, m, nq, tau);
+  TS_HIP(hipGetLastError());
+  return TS_OK;
+}

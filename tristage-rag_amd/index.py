@@ -1,0 +1,244 @@
+"""FlatIPIndex — the object that stands where the reference keeps its FAISS index.
+
+Reference seam: ``Stage1Retriever.faiss_index`` (reference
+src/stage1_retriever.py:126), built by ``faiss.IndexFlatIP(d)`` /
+``IndexIVFFlat`` (:256-283) and used through ``.add`` (:270,277,313),
+``.search`` (:380), ``.ntotal``.  This class keeps that duck type
+(``add``, ``search``, ``ntotal``, ``d``, ``reset``, ``reconstruct_n``) on top of
+the C ABI of libtristage.so; the search is always exact (FAISS ``IndexFlatIP``
+semantics — the reference's IVF variant above 1000 rows is an approximation of
+this result).
+
+Inputs may be numpy arrays (host pointers, FAISS style) or torch tensors on the
+index's GPU (device pointers, no copies).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+_NP_DTYPES = {np.dtype(np.float32): _lib.TS_F32, np.dtype(np.float16): _lib.TS_F16}
+_NAME_TO_DTYPE = {"f32": _lib.TS_F32, "fp32": _lib.TS_F32, "float32": _lib.TS_F32,
+                  "f16": _lib.TS_F16, "fp16": _lib.TS_F16, "float16": _lib.TS_F16,
+                  "bf16": _lib.TS_BF16, "bfloat16": _lib.TS_BF16}
+_DTYPE_NAME = {_lib.TS_F32: "f32", _lib.TS_F16: "f16", _lib.TS_BF16: "bf16"}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _tensor_dtype(t) -> int:
+    torch = _torch()
+    if t.dtype == torch.float32:
+        return _lib.TS_F32
+    if t.dtype == torch.float16:
+        return _lib.TS_F16
+    if t.dtype == torch.bfloat16:
+        return _lib.TS_BF16
+    raise TypeError(f"unsupported tensor dtype {t.dtype}")
+
+
+def _stream_ptr(device_index: int) -> int:
+    torch = _torch()
+    return int(torch.cuda.current_stream(device_index).cuda_stream)
+
+
+class FlatIPIndex:
+    """Exact inner-product index resident in MI355X HBM."""
+
+    def __init__(self, d: int, dtype: str = "f32", device: int = 0):
+        if dtype not in _NAME_TO_DTYPE:
+            raise ValueError(f"unknown storage dtype {dtype!r}")
+        self._lib = _lib.load()
+        self.d = int(d)
+        self.device = int(device)
+        self.storage_dtype = _DTYPE_NAME[_NAME_TO_DTYPE[dtype]]
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.ts_index_create(self.d, _NAME_TO_DTYPE[dtype],
+                                             _lib.TS_METRIC_INNER_PRODUCT, self.device,
+                                             ctypes.byref(self._h)))
+        self.is_trained = True  # FAISS attribute; a flat index needs no training
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ts_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- FAISS duck type --------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.ts_index_ntotal(self._h))
+
+    def train(self, x) -> None:  # IndexIVFFlat API used at reference :267; no-op here
+        return None
+
+    def reset(self) -> None:
+        _lib.check(self._lib.ts_index_reset(self._h))
+
+    def reserve(self, nrows: int) -> None:
+        _lib.check(self._lib.ts_index_reserve(self._h, int(nrows)))
+
+    def set_id_offset(self, offset: int) -> None:
+        _lib.check(self._lib.ts_index_set_id_offset(self._h, int(offset)))
+
+    def add(self, x, normalize: bool = False) -> None:
+        """Append rows ``x`` [n, d] (numpy float32/float16 or a CUDA tensor)."""
+        flags = _lib.TS_FLAG_NORMALIZE if normalize else 0
+        if _is_tensor(x):
+            if x.dim() != 2 or x.shape[1] != self.d:
+                raise ValueError(f"expected [n, {self.d}] rows, got {tuple(x.shape)}")
+            if not x.is_cuda:
+                return self.add(x.detach().float().numpy(), normalize=normalize)
+            if x.device.index != self.device:
+                raise ValueError("rows live on a different GPU than the index")
+            x = x.contiguous()
+            _lib.check(self._lib.ts_index_add(self._h, ctypes.c_void_p(x.data_ptr()), x.shape[0],
+                                              _tensor_dtype(x), flags,
+                                              ctypes.c_void_p(_stream_ptr(self.device))))
+            return None
+        x = np.ascontiguousarray(x)
+        if x.dtype not in _NP_DTYPES:
+            x = x.astype(np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"expected [n, {self.d}] rows, got {x.shape}")
+        _lib.check(self._lib.ts_index_add(self._h, x.ctypes.data_as(ctypes.c_void_p), x.shape[0],
+                                          _NP_DTYPES[x.dtype], flags | _lib.TS_FLAG_HOST_PTR,
+                                          None))
+        return None
+
+    def search(self, q, k: int, exact_dense: bool = False):
+        """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
+        numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out."""
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
+        if _is_tensor(q) and q.is_cuda:
+            torch = _torch()
+            if q.dim() != 2 or q.shape[1] != self.d:
+                raise ValueError(f"expected [B, {self.d}] queries, got {tuple(q.shape)}")
+            q = q.contiguous()
+            B = q.shape[0]
+            D = torch.empty((B, k), dtype=torch.float32, device=q.device)
+            I = torch.empty((B, k), dtype=torch.int64, device=q.device)
+            self._search_raw(q.data_ptr(), B, _tensor_dtype(q), k, D.data_ptr(), I.data_ptr(),
+                             flags, _stream_ptr(self.device))
+            return D, I
+        if _is_tensor(q):
+            q = q.detach().float().numpy()
+        q = np.ascontiguousarray(q)
+        if q.dtype not in _NP_DTYPES:
+            q = q.astype(np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"expected [B, {self.d}] queries, got {q.shape}")
+        B = q.shape[0]
+        D = np.empty((B, k), dtype=np.float32)
+        I = np.empty((B, k), dtype=np.int64)
+        self._search_raw(q.ctypes.data, B, _NP_DTYPES[q.dtype], k, D.ctypes.data, I.ctypes.data,
+                         flags | _lib.TS_FLAG_HOST_PTR, 0)
+        return D, I
+
+    def _search_raw(self, q_ptr: int, B: int, q_dtype: int, k: int, d_ptr: int, i_ptr: int,
+                    flags: int, stream: int) -> None:
+        code = self._lib.ts_index_search(self._h, ctypes.c_void_p(q_ptr), B, q_dtype, k,
+                                         ctypes.c_void_p(d_ptr), ctypes.c_void_p(i_ptr), flags,
+                                         ctypes.c_void_p(stream) if stream else None)
+        if code == _lib.TS_ERR_EMPTY:
+            # same exception type and text as reference src/stage1_retriever.py:370-371
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        _lib.check(code)
+
+    def reconstruct_n(self, i0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """Rows [i0, i0+n) as float32 (after storage rounding)."""
+        if n is None:
+            n = self.ntotal - i0
+        out = np.empty((n, self.d), dtype=np.float32)
+        if n:
+            _lib.check(self._lib.ts_index_reconstruct(self._h, int(i0), int(n),
+                                                      out.ctypes.data_as(ctypes.c_void_p),
+                                                      _lib.TS_FLAG_HOST_PTR, None))
+        return out
+
+    PHASES = ("qprep", "sample_scan", "tau", "filter_scan", "select", "dense", "_6", "_7")
+
+    def set_profiling(self, on: bool = True) -> None:
+        _lib.check(self._lib.ts_index_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self, reset: bool = True) -> dict:
+        """{phase: (total_ms, count)} measured with HIP events on the search stream."""
+        ms = (ctypes.c_double * 8)()
+        cnt = (ctypes.c_int64 * 8)()
+        _lib.check(self._lib.ts_index_get_timings(self._h, ms, cnt, 1 if reset else 0))
+        return {self.PHASES[i]: (float(ms[i]), int(cnt[i])) for i in range(6)}
+
+    def last_search_info(self) -> dict:
+        arr = (ctypes.c_int64 * 4)()
+        _lib.check(self._lib.ts_index_last_search_info(self._h, arr))
+        return {"path": ("dense", "filter", "filter+dense-fallback")[arr[0]],
+                "max_candidates": int(arr[1]), "sample_rows": int(arr[2]),
+                "sample_rank": int(arr[3])}
+
+
+def merge_topk(scores, ids, k: Optional[int] = None):
+    """Merge per-shard sorted lists ``scores``/``ids`` [R, B, k] (CUDA tensors)
+    into the global top-k [B, k] with the canonical (score desc, id asc) order."""
+    torch = _torch()
+    lib = _lib.load()
+    if scores.dim() != 3 or ids.shape != scores.shape:
+        raise ValueError("expected scores/ids of shape [R, B, k]")
+    R, B, kk = scores.shape
+    if k is not None and k != kk:
+        raise ValueError("k must equal the list length")
+    scores = scores.contiguous().float()
+    ids = ids.contiguous().to(torch.int64)
+    out_s = torch.empty((B, kk), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((B, kk), dtype=torch.int64, device=scores.device)
+    dev = scores.device.index
+    _lib.check(lib.ts_merge_topk(ctypes.c_void_p(scores.data_ptr()), ctypes.c_void_p(ids.data_ptr()),
+                                 R, B, kk, ctypes.c_void_p(out_s.data_ptr()),
+                                 ctypes.c_void_p(out_i.data_ptr()), dev,
+                                 ctypes.c_void_p(_stream_ptr(dev))))
+    return out_s, out_i
+
+
+def maxsim(q, docs, doc_offsets, mode: str = "maxsim"):
+    """Stage-2 scores of every candidate for one query (CUDA tensors).
+
+    q [Lq, H]; docs [sum(Ld), H] packed token embeddings; doc_offsets int32
+    [n_docs+1].  mode 'maxsim' | 'colbert' (reference src/stage2_rescorer.py:167-201)."""
+    torch = _torch()
+    lib = _lib.load()
+    if q.dtype != docs.dtype:
+        docs = docs.to(q.dtype)
+    q = q.contiguous()
+    docs = docs.contiguous()
+    doc_offsets = doc_offsets.to(device=q.device, dtype=torch.int32).contiguous()
+    n_docs = doc_offsets.numel() - 1
+    out = torch.empty((max(n_docs, 0),), dtype=torch.float32, device=q.device)
+    if n_docs <= 0:
+        return out
+    dev = q.device.index
+    _lib.check(lib.ts_maxsim(ctypes.c_void_p(q.data_ptr()), q.shape[0],
+                             ctypes.c_void_p(docs.data_ptr()),
+                             ctypes.c_void_p(doc_offsets.data_ptr()), n_docs, q.shape[1],
+                             _tensor_dtype(q), 0 if mode == "maxsim" else 1,
+                             ctypes.c_void_p(out.data_ptr()), dev,
+                             ctypes.c_void_p(_stream_ptr(dev))))
+    return out
