@@ -71,6 +71,15 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so
+    # (SONAME libamdhip64.so.7) and resolves it by file name, so it must be
+    # mapped BEFORE libtristage.so — whose DT_NEEDED libamdhip64.so.7 then binds
+    # to that same copy.  Loaded the other way round the process ends up with two
+    # runtimes and the second one sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C {CSRC_DIR}` "

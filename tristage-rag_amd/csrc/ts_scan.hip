@@ -26,6 +26,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SCAN_THREADS 512
 #define SCAN_WAVES (SCAN_THREADS / 64)
@@ -40,11 +41,12 @@ __device__ __forceinline__ void mma_group(f32x16& acc, const u32x4& a,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
         __builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
   } else {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
-          __builtin_bit_cast(float, a[t]), __builtin_bit_cast(float, b[t]),
-          acc, 0, 0, 0);
+    const f32x4 af = __builtin_bit_cast(f32x4, a);
+    const f32x4 bf = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
   }
 }
 
@@ -411,7 +413,8 @@ __global__ void reconstruct_kernel(const uint4* tiled, int64_t row0, int64_t n,
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = frag_k(dt, g, h, e);
-      if (k < dim) dst[k] = __builtin_bit_cast(float, v[e]);
+      const uint32_t w = v[e];
+      if (k < dim) dst[k] = __uint_as_float(w);
     }
   } else {
 #pragma unroll
