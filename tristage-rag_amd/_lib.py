@@ -11,7 +11,8 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtristage.so")
+# TRISTAGE_LIB: load another build of the same library (kernel-variant A/B runs)
+LIB_PATH = os.environ.get("TRISTAGE_LIB") or os.path.join(_HERE, "libtristage.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 TS_OK = 0

@@ -47,7 +47,9 @@ void ts_set_error(const char* fmt, ...);
 // (g*QH + hq)*64 + l holds, for query 32*hq + (l & 31), the same k's.
 // dim is zero-padded to a multiple of TS_RING groups so the scan kernel's
 // register ring never straddles a partial group.
+#ifndef TS_RING
 #define TS_RING 8          // k groups kept in flight per wave (1 KiB each)
+#endif
 #define TS_ROWS_PER_BLOCK 32
 #define TS_MAX_Q 64        // queries per scan pass (2 MFMA column halves)
 
@@ -103,6 +105,8 @@ enum { SCAN_DENSE = 0, SCAN_FILTER = 1 };
 
 int ts_launch_scan(const TsLayout& L, int mode, int qh, const ScanParams& p,
                    int num_cus, hipStream_t stream);
+// LDS bytes the scan kernel needs for qh*32 queries (Q image + candidate staging)
+size_t ts_scan_lds_bytes(const TsLayout& L, int qh);
 
 // rows [n, dim] (row-major, in_dtype) -> tiled storage at rows [row0, row0+n)
 int ts_launch_relayout(const TsLayout& L, const void* rows, int in_dtype,

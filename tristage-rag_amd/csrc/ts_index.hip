@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
@@ -174,9 +175,9 @@ extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metri
     return TS_ERR_INVALID;
   }
   TsLayout L = ts_make_layout(dim, storage_dtype);
-  if ((size_t)L.kg * 1024 > 160 * 1024) {
-    ts_set_error("dim %d with dtype %d needs %d KiB of LDS for 32 queries (max 160)", dim,
-                 storage_dtype, L.kg);
+  if (ts_scan_lds_bytes(L, 1) > 160 * 1024) {
+    ts_set_error("dim %d with dtype %d needs %zu bytes of LDS for 32 queries (max 163840)", dim,
+                 storage_dtype, ts_scan_lds_bytes(L, 1));
     return TS_ERR_UNSUPPORTED;
   }
   DeviceGuard g(device);
@@ -426,7 +427,9 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
   prof_mark(h, 2, s);
   // (2) per-query threshold = ~m-th best sample score
-  TS_CHECK(ts_launch_tau((const float*)h->sample.p, S, (uint32_t)S, m, nq, h->tau(), s));
+  static const bool dbg_tau_inf = getenv("TS_DEBUG_TAU_INF") != nullptr;  // tuning only
+  TS_CHECK(ts_launch_tau((const float*)h->sample.p, S, dbg_tau_inf ? 0xFFFFFFFFu : (uint32_t)S, m, nq,
+                         h->tau(), s));
   // (3) the full scan; only scores >= tau leave the registers
   sp.nwork = nblk;
   sp.blk_stride = 1;
@@ -491,7 +494,7 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
   }
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
-  const int qp = ((size_t)h->L.kg * 2 * 1024 <= 160 * 1024) ? 64 : 32;  // queries per pass
+  const int qp = (ts_scan_lds_bytes(h->L, 2) <= 160 * 1024) ? 64 : 32;  // queries per pass
   const size_t qrow = (size_t)h->L.dim * dtype_size(q_dtype);
   const void* dq = queries;
   float* ds = out_scores;

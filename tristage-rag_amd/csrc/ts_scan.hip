@@ -28,12 +28,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SCAN_THREADS
 #define SCAN_THREADS 512
+#endif
 #define SCAN_WAVES (SCAN_THREADS / 64)
+
+__device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
+#ifndef TS_PLAIN_LOADS  // non-temporal: the corpus is read once per batch, keep it out of L2/MALL
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 
 template <int DT>
 __device__ __forceinline__ void mma_group(f32x16& acc, const u32x4& a,
                                           const u32x4& b) {
+#ifdef DBG_NO_MFMA  // tuning experiments only: keep the operands live, skip the matrix op
+  acc[0] += __uint_as_float((a[0] ^ b[0]) & 0x007fffffu);
+  acc[1] += __uint_as_float((a[1] ^ b[1]) & 0x007fffffu);
+  acc[2] += __uint_as_float((a[2] ^ b[2]) & 0x007fffffu);
+  acc[3] += __uint_as_float((a[3] ^ b[3]) & 0x007fffffu);
+  return;
+#endif
   if constexpr (DT == TS_F16) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(
         __builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), acc, 0, 0, 0);
@@ -90,8 +107,25 @@ __device__ __forceinline__ void epilogue_dense(const ScanParams& p,
   }
 }
 
+// Survivors of the threshold test are parked in LDS and written to the
+// per-query candidate lists once, by the whole workgroup, when it has finished
+// streaming.  (Appending from the hot loop with returning global atomics costs
+// 27 % of the kernel at 10M x 768: each append stalls its wave for microseconds
+// behind the HBM stream — measured, DESIGN.md "candidate staging".)
+#define STAGE_CAP 2048
+struct StageLds {
+  uint32_t cnt;
+  uint32_t pad[3];
+  uint32_t qcnt[TS_MAX_Q];
+  uint32_t qbase[TS_MAX_Q];
+  uint32_t qoff[TS_MAX_Q];
+  float score[STAGE_CAP];
+  int32_t id[STAGE_CAP];
+  uint8_t q[STAGE_CAP];
+};
+
 template <int QH>
-__device__ __forceinline__ void epilogue_filter(const ScanParams& p,
+__device__ __forceinline__ void epilogue_filter(const ScanParams& p, StageLds* st,
                                                 const f32x16 (&acc)[QH],
                                                 const float (&tau)[QH],
                                                 int64_t blk, int lane) {
@@ -112,19 +146,49 @@ __device__ __forceinline__ void epilogue_filter(const ScanParams& p,
       mask |= ok ? (1u << r) : 0u;
     }
     if (mask) {
-      uint32_t slot = atomicAdd(&p.cand_cnt[q], (uint32_t)__builtin_popcount(mask));
-      float* cs = p.cand_score + (size_t)q * p.cand_cap;
-      int32_t* ci = p.cand_id + (size_t)q * p.cand_cap;
+      uint32_t slot = atomicAdd(&st->cnt, (uint32_t)__builtin_popcount(mask));  // LDS
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (mask & (1u << r)) {
-          if (slot < p.cand_cap) {
-            cs[slot] = acc[hq][r];
-            ci[slot] = (int32_t)(row_base + acc_row(r, lane));
+          const int32_t id = (int32_t)(row_base + acc_row(r, lane));
+          if (slot < STAGE_CAP) {
+            st->score[slot] = acc[hq][r];
+            st->id[slot] = id;
+            st->q[slot] = (uint8_t)q;
+          } else {
+            // staging area full (heavily clustered hits): append directly
+            const uint32_t g = atomicAdd(&p.cand_cnt[q], 1u);
+            if (g < p.cand_cap) {
+              p.cand_score[(size_t)q * p.cand_cap + g] = acc[hq][r];
+              p.cand_id[(size_t)q * p.cand_cap + g] = id;
+            }
           }
           ++slot;
         }
       }
+    }
+  }
+}
+
+// Workgroup-wide: move the staged survivors to the per-query lists.  One global
+// atomic per (workgroup, query) reserves the slots.
+__device__ __forceinline__ void flush_stage(const ScanParams& p, StageLds* st, int tid) {
+  __syncthreads();
+  const uint32_t n = st->cnt < STAGE_CAP ? st->cnt : STAGE_CAP;
+  if (n == 0) return;  // uniform: cnt is final after the barrier
+  if (tid < TS_MAX_Q) { st->qcnt[tid] = 0; st->qoff[tid] = 0; }
+  __syncthreads();
+  for (uint32_t e = tid; e < n; e += SCAN_THREADS) atomicAdd(&st->qcnt[st->q[e]], 1u);
+  __syncthreads();
+  if (tid < TS_MAX_Q && st->qcnt[tid] > 0)
+    st->qbase[tid] = atomicAdd(&p.cand_cnt[tid], st->qcnt[tid]);
+  __syncthreads();
+  for (uint32_t e = tid; e < n; e += SCAN_THREADS) {
+    const uint32_t q = st->q[e];
+    const uint32_t slot = st->qbase[q] + atomicAdd(&st->qoff[q], 1u);
+    if (slot < p.cand_cap) {
+      p.cand_score[(size_t)q * p.cand_cap + slot] = st->score[e];
+      p.cand_id[(size_t)q * p.cand_cap + slot] = st->id[e];
     }
   }
 }
@@ -146,11 +210,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int units = kg * QH * 64;
     for (int i = tid; i < units; i += SCAN_THREADS) qlds[i] = src[i];
   }
+  StageLds* st = reinterpret_cast<StageLds*>(smem + (size_t)kg * QH * 1024);
+  if constexpr (MODE == SCAN_FILTER) {
+    if (tid == 0) st->cnt = 0;
+  }
   __syncthreads();
 
   const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
   int64_t w = (int64_t)blockIdx.x * SCAN_WAVES + wave;
-  if (w >= p.nwork) return;
+  if (w < p.nwork) {  // (waves without work still join the final flush)
 
   float tau[QH];
   if constexpr (MODE == SCAN_FILTER) {
@@ -165,7 +233,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
 
   u32x4 ring[TS_RING];
 #pragma unroll
-  for (int i = 0; i < TS_RING; ++i) ring[i] = cur[(size_t)i * 64];
+  for (int i = 0; i < TS_RING; ++i) ring[i] = stream_load(cur + (size_t)i * 64);
 
   const u32x4* ql = qlds + lane;
 
@@ -188,12 +256,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
       for (int i = 0; i < TS_RING; ++i) {
 #pragma unroll
         for (int hq = 0; hq < QH; ++hq) {
+#ifdef DBG_NO_LDS
+          const u32x4 b = ring[(i + 1) % TS_RING];
+#else
           const u32x4 b = ql[(size_t)((g0 + i) * QH + hq) * 64];
+#endif
           mma_group<DT>(acc[hq], ring[i], b);
         }
         // refill the slot just consumed; the barrier keeps the compiler from
         // clustering the ring's loads (which would drain vmcnt to 0 mid-loop)
-        ring[i] = cur[(size_t)(g0 + i + TS_RING) * 64];
+        ring[i] = stream_load(cur + (size_t)(g0 + i + TS_RING) * 64);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -202,29 +274,39 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     for (int i = 0; i < TS_RING; ++i) {
 #pragma unroll
       for (int hq = 0; hq < QH; ++hq) {
+#ifdef DBG_NO_LDS
+        const u32x4 b = ring[(i + 1) % TS_RING];
+#else
         const u32x4 b = ql[(size_t)((g0 + i) * QH + hq) * 64];
+#endif
         mma_group<DT>(acc[hq], ring[i], b);
       }
-      ring[i] = nxt[(size_t)i * 64];
+      ring[i] = stream_load(nxt + (size_t)i * 64);
       __builtin_amdgcn_sched_barrier(0);
     }
 
     if constexpr (MODE == SCAN_DENSE)
       epilogue_dense<QH>(p, acc, w, blk, lane);
     else
-      epilogue_filter<QH>(p, acc, tau, blk, lane);
+      epilogue_filter<QH>(p, st, acc, tau, blk, lane);
 
     if (!has_next) break;
     w = wn;
     blk = blkn;
     cur = nxt;
   }
+  }  // w < nwork
+  if constexpr (MODE == SCAN_FILTER) flush_stage(p, st, tid);
+}
+
+size_t ts_scan_lds_bytes(const TsLayout& L, int qh) {
+  return (size_t)L.kg * qh * 1024 + sizeof(StageLds);
 }
 
 template <int DT, int QH, int MODE>
 static int launch_scan_t(const TsLayout& L, const ScanParams& p, int num_cus,
                          hipStream_t stream) {
-  const size_t lds = (size_t)L.kg * QH * 1024;
+  const size_t lds = (size_t)L.kg * QH * 1024 + (MODE == SCAN_FILTER ? sizeof(StageLds) : 0);
   auto kern = scan_kernel<DT, QH, MODE>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
@@ -262,7 +344,7 @@ static int launch_scan_dt(const TsLayout& L, int mode, int qh,
 int ts_launch_scan(const TsLayout& L, int mode, int qh, const ScanParams& p,
                    int num_cus, hipStream_t stream) {
   if (p.nwork <= 0) return TS_OK;
-  if ((size_t)L.kg * qh * 1024 > 160 * 1024) {
+  if (ts_scan_lds_bytes(L, qh) > 160 * 1024) {
     ts_set_error("dimension %d too large for the LDS-resident query image", L.dim);
     return TS_ERR_UNSUPPORTED;
   }

@@ -264,6 +264,8 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, i
     return;
   }
   const float* s = sample + (int64_t)q * ld;
+  const bool dbg_inf = (n == 0xFFFFFFFFu);  // tuning experiments: nothing passes
+  if (dbg_inf) n = 0;
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   for (uint32_t i = tid; i < n; i += SEL_THREADS) {
     uint32_t k = f2key(s[i]);
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, i
     if (idx >= P) idx = P - 1;
     const uint32_t k = keys[idx];
     tau[q] = (k == 0u) ? NEG_MAX : key2f(k);
+    if (dbg_inf) tau[q] = 3.402823466e38f;
   }
 }
 
