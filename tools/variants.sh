@@ -9,6 +9,6 @@ print('$1', d['value'], d['ms_per_step'], d['roofline']['avg_kernel_ms'], d['roo
 }
 for round in 1 2; do
 run "default(nt) r$round" $PWD/tristage-rag_amd/libtristage.so X=1
-run "plain r$round" $PWD/tristage-rag_amd/variants_P.so X=1
+
 done
 cat gpurun_out/variants.log

@@ -147,7 +147,9 @@ struct SelParams {
   int32_t* out_ids32;      // intermediate output (local ids), or null
   int64_t out_stride;
   int64_t id_offset;
-  uint32_t* status;        // optional
+  uint32_t* status;        // optional device status word (TS_STATUS_* bits are OR-ed in)
+  uint32_t* host_report;   // optional, device view of pinned host memory:
+                           // [q] = candidate count of query q, [64] |= status bits
 };
 
 int ts_launch_select(const SelParams& p, int nq, hipStream_t stream);

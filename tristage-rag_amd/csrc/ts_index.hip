@@ -97,7 +97,8 @@ struct ts_index {
   // workspace (grown on demand, never inside a steady-state search)
   DevBuf qimg, small, cand_score, cand_id, sample, dense, list_score, list_id;
   DevBuf stage, den, qstage, out_s, out_i;
-  uint32_t* host_status = nullptr;  // pinned
+  uint32_t* host_status = nullptr;  // pinned + mapped: written by the select kernel
+  uint32_t* host_status_dev = nullptr;  // device view of host_status
   // optional per-phase timing with HIP events on the caller's stream
   bool profiling = false;
   hipEvent_t ev[TS_NPHASE + 1] = {};
@@ -191,8 +192,10 @@ extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metri
     h->num_cus = prop.multiProcessorCount;
   int st = ensure(h->small, 4096);
   if (st == TS_OK) st = ensure(h->qimg, (size_t)L.kg * 2 * 1024);
-  if (st == TS_OK && hipHostMalloc((void**)&h->host_status, 512, hipHostMallocDefault) != hipSuccess) {
-    ts_set_error("hipHostMalloc failed");
+  if (st == TS_OK &&
+      (hipHostMalloc((void**)&h->host_status, 512, hipHostMallocMapped) != hipSuccess ||
+       hipHostGetDevicePointer((void**)&h->host_status_dev, h->host_status, 0) != hipSuccess)) {
+    ts_set_error("hipHostMalloc(mapped) failed");
     st = TS_ERR_HIP;
   }
   if (st != TS_OK) {
@@ -402,6 +405,10 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   }
   // ---- filter path: sample -> thresholds -> fused scan+filter -> select
   int64_t nsb = std::max(kMinSampleRows, N / kSampleDiv) / TS_ROWS_PER_BLOCK;
+  // one sample block per scan wave (8 waves per CU): a ragged last round would
+  // make the short sample scan ~1.7x longer than it has to be
+  const int64_t round = (int64_t)h->num_cus * 8;
+  if (nsb > round) nsb -= nsb % round;
   nsb = std::min(nsb, nblk);
   const int64_t sstride = nblk / nsb;
   const int64_t S = nsb * TS_ROWS_PER_BLOCK;
@@ -457,10 +464,12 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   p.out_stride = k;
   p.id_offset = h->id_offset;
   p.status = h->status();
+  // the select kernel reports the candidate counts and the status word straight
+  // into mapped host memory: no copy kernel between it and the sync
+  p.host_report = h->host_status_dev;
+  for (int i = 0; i < 65; ++i) h->host_status[i] = 0;
   TS_CHECK(ts_launch_select(p, nq, s));
   prof_mark(h, -1, s);
-  // the 64 candidate counts and the status word come back together
-  TS_HIP(hipMemcpyAsync(h->host_status, h->cand_cnt(), 65 * 4, hipMemcpyDeviceToHost, s));
   TS_HIP(hipStreamSynchronize(s));
   prof_collect(h);
   uint32_t maxc = 0;

@@ -208,7 +208,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.qimg);
     const int units = kg * QH * 64;
-    for (int i = tid; i < units; i += SCAN_THREADS) qlds[i] = src[i];
+    // 8 independent loads in flight per thread (a one-load-at-a-time copy of the
+    // 96 KiB image costs ~18 us of serial L2 latency per workgroup)
+    for (int i0 = tid; i0 < units; i0 += 8 * SCAN_THREADS) {
+      u32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * SCAN_THREADS;
+        t[j] = (i < units) ? src[i] : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * SCAN_THREADS;
+        if (i < units) qlds[i] = t[j];
+      }
+    }
   }
   StageLds* st = reinterpret_cast<StageLds*>(smem + (size_t)kg * QH * 1024);
   if constexpr (MODE == SCAN_FILTER) {

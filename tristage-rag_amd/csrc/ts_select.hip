@@ -8,13 +8,18 @@
 // so "larger key" == "better" and keys are unique (tiebreak = row id, or the
 // position in the concatenated lists for the int64-id merge, where exact
 // score ties are then resolved by comparing the real ids).
-//   phase 1 (only when the entries do not fit LDS): MSB-first 8-bit radix
-//            select over the keys in global memory -> key of the k-th best
-//   phase 2: compact the survivors (key >= T) into LDS
-//   phase 3: bitonic sort in LDS, write the first k.
+//   phase 1  entries -> LDS.  If they do not fit (dense scores of a large
+//            chunk), an MSB-first 8-bit radix select over global memory finds
+//            the key of the k-th best first and only the survivors are kept.
+//   phase 2  if far more entries than k sit in LDS (the usual case after the
+//            fused scan+filter: ~5 k candidates for k = 1000), a radix select
+//            IN LDS finds the k-th key and the k survivors are compacted;
+//   phase 3  bitonic sort of what is left (~k entries), write the first k.
 #include "ts_common.h"
 
 #define SEL_THREADS 1024
+#define SEL_OUT_CAP 2048   // survivors kept by the in-LDS select (k <= 2048)
+#define SEL_TIE_CAP 1024   // MERGE64: entries whose score equals the k-th score
 #define NEG_MAX (-3.402823466e38f)
 
 __device__ __forceinline__ uint32_t f2key(float f) {
@@ -37,8 +42,7 @@ __device__ __forceinline__ int64_t entry_addr(const SelParams& p, int64_t qbase,
 }
 
 template <int MODE>
-__device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase,
-                                             uint32_t i) {
+__device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase, uint32_t i) {
   const int64_t a = entry_addr(p, qbase, i);
   const float s = p.scores[a];
   uint32_t tb;
@@ -56,8 +60,8 @@ __device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase,
 }
 
 template <int MODE>
-__device__ __forceinline__ bool key_before(const SelParams& p, int64_t qbase,
-                                           uint64_t a, uint64_t b) {
+__device__ __forceinline__ bool key_before(const SelParams& p, int64_t qbase, uint64_t a,
+                                           uint64_t b) {
   // true when a must come before b in the output (a is "better")
   if constexpr (MODE == SEL_MERGE64) {
     const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
@@ -71,12 +75,80 @@ __device__ __forceinline__ bool key_before(const SelParams& p, int64_t qbase,
   }
 }
 
+// ---- shared pieces ----------------------------------------------------------
+// one histogram vote per (thread, key); whole waves that agree on the digit
+// (concentrated scores) add once
+__device__ __forceinline__ void hist_vote(uint32_t* hist, bool in, uint32_t digit, int tid) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+  if (m == 0ull) return;
+  const int src = __builtin_ctzll(m);
+  const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
+  const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
+  if (same == m) {
+    if ((tid & 63) == src) atomicAdd(&hist[d0], (uint32_t)__builtin_popcountll(m));
+  } else if (in) {
+    atomicAdd(&hist[digit], 1u);
+  }
+}
+
+// hist[256] holds the votes of one radix pass; finds the bin that contains the
+// krem-th largest entry.  sh[0] = bin, sh[1] = rank still wanted inside the bin,
+// sh[2] = 1 if the whole bin is wanted.  Must be called by all SEL_THREADS
+// threads, after a barrier that made hist visible; ends with a barrier.
+__device__ __forceinline__ void find_digit(const uint32_t* hist, uint32_t krem, uint32_t* sh,
+                                           uint32_t* wtot, int tid) {
+  uint32_t v = 0, own = 0;
+  const int lane = tid & 63, wv = tid >> 6;
+  if (tid < 256) {
+    own = hist[tid];
+    v = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_down((int)v, off, 64);
+      if (lane + off < 64) v += t;
+    }
+    if (lane == 0) wtot[wv] = v;  // votes in bins [64*wv, 64*wv+63]
+  }
+  __syncthreads();
+  if (tid < 256) {
+    for (int w2 = wv + 1; w2 < 4; ++w2) v += wtot[w2];  // v = votes in bins >= tid
+    const uint32_t above = v - own;
+    if (v >= krem && above < krem) {
+      sh[0] = (uint32_t)tid;
+      sh[1] = krem - above;
+      sh[2] = (own == krem - above) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+}
+
+template <int MODE>
+__device__ __forceinline__ void bitonic_desc(const SelParams& p, int64_t qbase, uint64_t* keys,
+                                             uint32_t P, int tid) {
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+        const uint32_t i = 2 * t - (t & (stride - 1));
+        const uint32_t j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint64_t a = keys[i], b = keys[j];
+        const bool swap = desc ? key_before<MODE>(p, qbase, b, a) : key_before<MODE>(p, qbase, a, b);
+        if (swap) { keys[i] = b; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32_t lds_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + (size_t)lds_keys * 8);  // [256]
-  uint32_t* sh = hist + 256;  // [8] scratch
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                 // [lds_keys]
+  uint64_t* outk = keys + lds_keys;                                   // [SEL_OUT_CAP]
+  uint64_t* ties = outk + SEL_OUT_CAP;                                // [SEL_TIE_CAP] (MERGE64)
+  uint32_t* hist = reinterpret_cast<uint32_t*>(ties + (MODE == SEL_MERGE64 ? SEL_TIE_CAP : 0));
+  uint32_t* sh = hist + 256;   // [8]
+  uint32_t* wtot = sh + 8;     // [4]
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t qbase = (int64_t)q * p.stride;
@@ -85,18 +157,21 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
   if (p.n_per_q) {
     const uint32_t c = p.n_per_q[q];
     n = c < p.n_cap ? c : p.n_cap;
-    if (tid == 0 && p.status) {
+    if (tid == 0) {
       uint32_t st = 0;
       if (c > p.n_cap) st |= TS_STATUS_OVERFLOW;
       if (c < p.need) st |= TS_STATUS_SHORT;
-      if (st) atomicOr(p.status, st);
+      if (st && p.status) atomicOr(p.status, st);
+      if (p.host_report) {  // mapped pinned host memory: [0..63] counts, [64] status
+        p.host_report[q] = c;
+        if (st) atomicOr(&p.host_report[64], st);
+      }
     }
   }
   const uint32_t kk = (uint32_t)p.k < n ? (uint32_t)p.k : n;
 
-  // ---- phase 1: radix select of the kk-th largest key (only if n > LDS room)
-  uint64_t T = 0ull;
-  uint32_t count;  // survivors
+  // ---- phase 1: entries -> LDS (through a global radix select if too many)
+  uint32_t count;
   if (n > lds_keys) {
     uint64_t prefix = 0ull;
     int bits_done = 0;
@@ -116,35 +191,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
         for (int u = 0; u < 4; ++u) {
           const uint32_t i = base + u * SEL_THREADS + tid;
           const bool in = (i < n) && (bits_done == 0 || (kx[u] >> (64 - bits_done)) == prefix);
-          const uint32_t digit = (uint32_t)(kx[u] >> shift) & 0xFFu;
-          // wave-uniform fast path: concentrated scores put whole waves in one bin
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-          if (m) {
-            const int src = __builtin_ctzll(m);
-            const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
-            const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
-            if (same == m) {
-              if ((tid & 63) == src) atomicAdd(&hist[d0], (uint32_t)__builtin_popcountll(m));
-            } else if (in) {
-              atomicAdd(&hist[digit], 1u);
-            }
-          }
+          hist_vote(hist, in, (uint32_t)(kx[u] >> shift) & 0xFFu, tid);
         }
       }
       __syncthreads();
-      if (tid == 0) {
-        uint32_t cum = 0;
-        int d = 255;
-        for (; d > 0; --d) {
-          const uint32_t c = hist[d];
-          if (cum + c >= krem) break;
-          cum += c;
-        }
-        sh[0] = (uint32_t)d;
-        sh[1] = krem - cum;
-        sh[2] = (hist[d] == krem - cum) ? 1u : 0u;
-      }
-      __syncthreads();
+      find_digit(hist, krem, sh, wtot, tid);
       prefix = (prefix << 8) | (uint64_t)sh[0];
       krem = sh[1];
       bits_done += 8;
@@ -152,8 +203,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
       __syncthreads();
       if (done) break;
     }
-    T = (bits_done == 64) ? prefix : (prefix << (64 - bits_done));
-    // ---- phase 2: compact survivors
+    const uint64_t T = (bits_done == 64) ? prefix : (prefix << (64 - bits_done));
     if (tid == 0) sh[3] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += SEL_THREADS) {
@@ -168,32 +218,99 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
   } else {
     for (uint32_t i = tid; i < n; i += SEL_THREADS) keys[i] = load_key<MODE>(p, qbase, i);
     count = n;
+    __syncthreads();
   }
 
-  // ---- phase 3: bitonic sort (descending by key_before) over P >= count
-  uint32_t P = 2;
-  while (P < count) P <<= 1;
-  for (uint32_t i = count + tid; i < P; i += SEL_THREADS) keys[i] = 0ull;
-  __syncthreads();
-  for (uint32_t size = 2; size <= P; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
-        const uint32_t i = 2 * t - (t & (stride - 1));
-        const uint32_t j = i + stride;
-        const bool desc = (i & size) == 0;
-        const uint64_t a = keys[i], b = keys[j];
-        const bool swap = desc ? key_before<MODE>(p, qbase, b, a)
-                               : key_before<MODE>(p, qbase, a, b);
-        if (swap) { keys[i] = b; keys[j] = a; }
+  // ---- phase 2: many more entries than wanted -> radix select inside LDS
+  uint64_t* fin = keys;
+  uint32_t pk = 2;
+  while (pk < kk) pk <<= 1;
+  if (kk >= 1 && pk <= SEL_OUT_CAP && count > 2 * pk) {
+    uint64_t prefix = 0ull;
+    int bits_done = 0;
+    uint32_t krem = kk;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < count; base += SEL_THREADS) {
+        const uint32_t i = base + tid;
+        const uint64_t key = (i < count) ? keys[i] : 0ull;
+        const bool in = (i < count) && (bits_done == 0 || (key >> (64 - bits_done)) == prefix);
+        hist_vote(hist, in, (uint32_t)(key >> shift) & 0xFFu, tid);
       }
       __syncthreads();
+      find_digit(hist, krem, sh, wtot, tid);
+      prefix = (prefix << 8) | (uint64_t)sh[0];
+      krem = sh[1];
+      bits_done += 8;
+      const bool done = sh[2] != 0;
+      __syncthreads();
+      if (done) break;
+      if (MODE == SEL_MERGE64 && bits_done == 32) break;  // score decided; ties by real id below
     }
+    const uint64_t T = (bits_done == 64) ? prefix : (prefix << (64 - bits_done));
+    const bool whole = sh[2] != 0;  // every entry of the last bin is wanted: survivors = key >= T
+    __syncthreads();
+    if (tid == 0) { sh[3] = 0; sh[4] = 0; }
+    __syncthreads();
+    if constexpr (MODE == SEL_MERGE64) {
+      // survivors = scores above the k-th score, plus, of the entries AT that score,
+      // the ones with the smallest ids (the key's low half is only a position)
+      const uint32_t sT = (uint32_t)(T >> 32);
+      for (uint32_t i = tid; i < count; i += SEL_THREADS) {
+        const uint64_t key = keys[i];
+        if (key == 0ull) continue;
+        const uint32_t sk = (uint32_t)(key >> 32);
+        if (whole ? (key >= T) : (sk > sT)) {
+          const uint32_t pos = atomicAdd(&sh[3], 1u);
+          if (pos < SEL_OUT_CAP) outk[pos] = key;
+        } else if (!whole && sk == sT) {
+          const uint32_t pos = atomicAdd(&sh[4], 1u);
+          if (pos < SEL_TIE_CAP) ties[pos] = key;
+        }
+      }
+      __syncthreads();
+      uint32_t c1 = sh[3], nt = sh[4];
+      if (nt > SEL_TIE_CAP) nt = SEL_TIE_CAP;  // > 1024 exact ties at the boundary: by position
+      if (nt > 0) {
+        uint32_t pt = 2;
+        while (pt < nt) pt <<= 1;
+        for (uint32_t i = nt + tid; i < pt; i += SEL_THREADS) ties[i] = 0ull;
+        __syncthreads();
+        bitonic_desc<MODE>(p, qbase, ties, pt, tid);
+        const uint32_t want = kk > c1 ? kk - c1 : 0;
+        for (uint32_t i = tid; i < nt && i < want; i += SEL_THREADS)
+          if (c1 + i < SEL_OUT_CAP) outk[c1 + i] = ties[i];
+        c1 += (want < nt ? want : nt);
+      }
+      count = c1 < SEL_OUT_CAP ? c1 : SEL_OUT_CAP;
+    } else {
+      for (uint32_t i = tid; i < count; i += SEL_THREADS) {
+        const uint64_t key = keys[i];
+        if (key >= T && key != 0ull) {
+          const uint32_t pos = atomicAdd(&sh[3], 1u);
+          if (pos < SEL_OUT_CAP) outk[pos] = key;
+        }
+      }
+      __syncthreads();
+      count = sh[3] < SEL_OUT_CAP ? sh[3] : SEL_OUT_CAP;
+    }
+    fin = outk;
+    __syncthreads();
   }
+
+  // ---- phase 3: bitonic sort of the remaining entries, best first
+  uint32_t P = 2;
+  while (P < count) P <<= 1;
+  for (uint32_t i = count + tid; i < P; i += SEL_THREADS) fin[i] = 0ull;
+  __syncthreads();
+  bitonic_desc<MODE>(p, qbase, fin, P, tid);
 
   // ---- output
   float* os = p.out_scores + (int64_t)q * p.out_stride;
   for (uint32_t i = tid; i < (uint32_t)p.k; i += SEL_THREADS) {
-    const uint64_t key = (i < count) ? keys[i] : 0ull;
+    const uint64_t key = (i < count) ? fin[i] : 0ull;
     float s = NEG_MAX;
     int64_t id = -1;
     if (i < kk && key != 0ull) {
@@ -203,31 +320,33 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
       else id = (int64_t)tb;
     }
     os[i] = s;
-    if (p.out_ids64) p.out_ids64[(int64_t)q * p.out_stride + i] = (id < 0) ? -1 : (MODE == SEL_MERGE64 ? id : id + p.id_offset);
+    if (p.out_ids64)
+      p.out_ids64[(int64_t)q * p.out_stride + i] =
+          (id < 0) ? -1 : (MODE == SEL_MERGE64 ? id : id + p.id_offset);
     if (p.out_ids32) p.out_ids32[(int64_t)q * p.out_stride + i] = (int32_t)id;
   }
 }
 
 template <int MODE>
 static int launch_select_t(const SelParams& p, int nq, hipStream_t stream) {
-  // LDS: enough 64-bit keys for the entries (or for k when radix-selecting)
+  // LDS: enough 64-bit keys for the entries (or for k when radix-selecting in global)
   uint32_t nmax = p.n_per_q ? p.n_cap : p.n;
   uint32_t need = nmax;
   if (need > TS_SEL_LDS_KEYS) need = TS_SEL_LDS_KEYS;
   uint32_t lds_keys = 2;
   while (lds_keys < need) lds_keys <<= 1;
   if (nmax > TS_SEL_LDS_KEYS) {
-    // radix path: room for the k survivors, rounded up to a power of two
     uint32_t kk = (uint32_t)p.k;
     if (kk > TS_SEL_LDS_KEYS) {
-      ts_set_error("k=%d exceeds the supported maximum %d for %u entries", p.k,
-                   TS_SEL_LDS_KEYS, nmax);
+      ts_set_error("k=%d exceeds the supported maximum %d for %u entries", p.k, TS_SEL_LDS_KEYS,
+                   nmax);
       return TS_ERR_UNSUPPORTED;
     }
     lds_keys = 2;
     while (lds_keys < kk) lds_keys <<= 1;
   }
-  const size_t lds = (size_t)lds_keys * 8 + 256 * 4 + 8 * 4;
+  const size_t lds = ((size_t)lds_keys + SEL_OUT_CAP + (MODE == SEL_MERGE64 ? SEL_TIE_CAP : 0)) * 8 +
+                     (256 + 8 + 4) * 4;
   auto kern = select_kernel<MODE>;
   TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -248,15 +367,18 @@ int ts_launch_select(const SelParams& p, int nq, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ tau
-// Per-query threshold from a dense sample: every thread keeps the 4 largest
-// keys of its strided share, the 4096 survivors are sorted in LDS and the
-// m-th is taken.  This is a lower bound of the exact m-th largest (it can only
-// miss large values when one thread sees more than four of them), which is the
-// safe direction: a lower threshold admits more candidates, never fewer.
+// Per-query threshold from the dense sample scores: roughly the m-th largest.
+// Every thread keeps the KEEP largest keys of its share; the m-th largest of
+// those 1024*KEEP survivors is a LOWER bound of the exact m-th largest (large
+// values are only lost when one thread sees more than KEEP of them), which is
+// the safe direction: a lower threshold admits more candidates, never fewer.
+// The exactness of the search never depends on this value (ts_index.hip
+// verifies the candidate counts).
+template <int KEEP>
 __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, int64_t ld,
                                                           uint32_t n, uint32_t m, int nq,
                                                           float* tau) {
-  __shared__ uint32_t keys[4 * SEL_THREADS];
+  __shared__ __attribute__((aligned(16))) uint32_t keys[KEEP * SEL_THREADS];
   const int q = blockIdx.x;
   const int tid = threadIdx.x;
   if (q >= nq) {
@@ -267,21 +389,49 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, i
   const bool dbg_inf = (n == 0xFFFFFFFFu);  // tuning experiments: nothing passes
   if (dbg_inf) n = 0;
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  for (uint32_t i = tid; i < n; i += SEL_THREADS) {
-    uint32_t k = f2key(s[i]);
-    if (k > a3) {
-      if (k > a0) { a3 = a2; a2 = a1; a1 = a0; a0 = k; }
-      else if (k > a1) { a3 = a2; a2 = a1; a1 = k; }
-      else if (k > a2) { a3 = a2; a2 = k; }
-      else a3 = k;
+  auto take = [&](float f) {
+    const uint32_t k = f2key(f);
+    if constexpr (KEEP == 1) {
+      a0 = k > a0 ? k : a0;
+    } else {
+      if (k > a3) {
+        if (k > a0) { a3 = a2; a2 = a1; a1 = a0; a0 = k; }
+        else if (k > a1) { a3 = a2; a2 = a1; a1 = k; }
+        else if (k > a2) { a3 = a2; a2 = k; }
+        else a3 = k;
+      }
+    }
+  };
+  const uint32_t n4 = ((ld & 3) == 0) ? (n & ~3u) : 0u;  // float4 part (rows are 16-byte aligned)
+  // 8 independent 16-byte loads in flight per thread: one workgroup per query
+  // means this loop is latency-bound, not bandwidth-bound
+  for (uint32_t i0 = 0; i0 < n4; i0 += 32 * SEL_THREADS) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t i = i0 + 4 * (tid + j * SEL_THREADS);
+      v[j] = (i < n4) ? *reinterpret_cast<const float4*>(s + i)
+                      : make_float4(NEG_MAX, NEG_MAX, NEG_MAX, NEG_MAX);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t i = i0 + 4 * (tid + j * SEL_THREADS);
+      if (i < n4) { take(v[j].x); take(v[j].y); take(v[j].z); take(v[j].w); }
     }
   }
+  for (uint32_t i = n4 + tid; i < n; i += SEL_THREADS) take(s[i]);
+
   keys[tid] = a0;
-  keys[SEL_THREADS + tid] = a1;
-  keys[2 * SEL_THREADS + tid] = a2;
-  keys[3 * SEL_THREADS + tid] = a3;
+  if constexpr (KEEP == 4) {
+    keys[SEL_THREADS + tid] = a1;
+    keys[2 * SEL_THREADS + tid] = a2;
+    keys[3 * SEL_THREADS + tid] = a3;
+  }
   __syncthreads();
-  const uint32_t P = 4 * SEL_THREADS;
+  constexpr uint32_t P = KEEP * SEL_THREADS;
+  uint32_t idx = m ? m - 1 : 0;
+  if (idx >= P) idx = P - 1;
+  // bitonic sort, descending (1024 keys: 55 stages of half a compare-exchange per thread)
   for (uint32_t size = 2; size <= P; size <<= 1) {
     for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
       for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
@@ -295,18 +445,20 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, i
     }
   }
   if (tid == 0) {
-    uint32_t idx = m ? m - 1 : 0;
-    if (idx >= P) idx = P - 1;
     const uint32_t k = keys[idx];
-    tau[q] = (k == 0u) ? NEG_MAX : key2f(k);
-    if (dbg_inf) tau[q] = 3.402823466e38f;
+    tau[q] = dbg_inf ? 3.402823466e38f : ((k == 0u) ? NEG_MAX : key2f(k));
   }
 }
 
-int ts_launch_tau(const float* sample, int64_t ld, uint32_t n, uint32_t m, int nq,
-                  float* tau, hipStream_t stream) {
-  hipLaunchKernelGGL(tau_kernel, dim3(TS_MAX_Q), dim3(SEL_THREADS), 0, stream, sample,
-                     ld, n, m, nq, tau);
+int ts_launch_tau(const float* sample, int64_t ld, uint32_t n, uint32_t m, int nq, float* tau,
+                  hipStream_t stream) {
+  // one key per thread is enough while the wanted rank is far below 1024
+  if (m <= 64)
+    hipLaunchKernelGGL(tau_kernel<1>, dim3(TS_MAX_Q), dim3(SEL_THREADS), 0, stream, sample, ld, n,
+                       m, nq, tau);
+  else
+    hipLaunchKernelGGL(tau_kernel<4>, dim3(TS_MAX_Q), dim3(SEL_THREADS), 0, stream, sample, ld, n,
+                       m, nq, tau);
   TS_HIP(hipGetLastError());
   return TS_OK;
 }

@@ -1,0 +1,337 @@
+"""Transformer encoders behind the three stages, on PyTorch-ROCm.
+
+The reference reaches its encoders through sentence-transformers
+(``SentenceTransformer.encode`` at reference src/stage1_retriever.py:236-248 and
+benchmark/tristage_mteb_model.py:187-193, ``CrossEncoder.predict`` at
+src/stage3_reranker.py:127-131).  That package is a third-party dependency
+(requirements.txt:3, ">=2.0.0", unpinned) and is not installed here, so its
+published behaviour is restated on top of ``transformers``:
+
+SentenceEncoder.encode      tokenise (pad to longest, truncate to max_seq_length)
+                            -> AutoModel -> pooling module (mean over the
+                            attention mask by default; cls / max) -> optional Dense
+                            layers -> optional L2 normalisation; inputs are
+                            processed in length-sorted batches and returned in
+                            the caller's order, float32.
+CrossEncoderModel.predict   tokenise (query, doc) pairs -> AutoModelForSequence-
+                            Classification -> logits -> activation (Sigmoid for a
+                            single label unless the checkpoint's config names
+                            another one) -> float32 scores.
+
+Model sources, in order: a local directory (``<cache_dir>/<basename>`` first, then
+``<cache_dir>/<name>``, the reference's lookup at src/stage1_retriever.py:148-151),
+else the hub name (needs network; never attempted in tests), or the offline spec
+``random:<arch>[:hidden[:layers[:heads]]]`` which builds a randomly initialised
+model of that architecture with a deterministic hashing tokenizer — used for the
+throughput benchmarks and tests, where no weights are available ("parity
+unpinned" for real checkpoints: no weights exist on disk).
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+import zlib
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def resolve_device(device: str = "auto") -> str:
+    if device == "auto":
+        return "cuda" if torch.cuda.is_available() else "cpu"
+    return device
+
+
+def local_model_dir(model_name: str, cache_dir: str) -> Optional[str]:
+    """reference src/stage1_retriever.py:148-151 (same rule in stage 2 and 3)."""
+    base = os.path.join(cache_dir, os.path.basename(model_name))
+    legacy = os.path.join(cache_dir, model_name)
+    if os.path.isdir(base):
+        return base
+    if os.path.isdir(legacy):
+        return legacy
+    if os.path.isdir(model_name):
+        return model_name
+    return None
+
+
+# --------------------------------------------------------------------------- tokenizer
+class HashTokenizer:
+    """Deterministic offline tokenizer: lower-cased word / punctuation pieces hashed
+    into a fixed vocabulary, BERT-style special tokens ([CLS]=101, [SEP]=102, [PAD]=0).
+    Same call surface as the HF tokenizers for the arguments the reference uses
+    (text, text_pair, truncation, padding, max_length, return_tensors="pt")."""
+
+    pad_token_id, cls_token_id, sep_token_id = 0, 101, 102
+
+    def __init__(self, vocab_size: int = 30522, model_max_length: int = 512):
+        self.vocab_size = int(vocab_size)
+        self.model_max_length = int(model_max_length)
+
+    def _ids(self, text: str) -> List[int]:
+        pieces = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", text.lower())
+        span = self.vocab_size - 1000
+        return [1000 + (zlib.crc32(p.encode("utf-8")) % span) for p in pieces]
+
+    def __call__(self, text, text_pair=None, truncation=True, padding=False, max_length=None,
+                 return_tensors=None, **_):
+        single = isinstance(text, str)
+        texts = [text] if single else list(text)
+        pairs = None
+        if text_pair is not None:
+            pairs = [text_pair] if isinstance(text_pair, str) else list(text_pair)
+        max_length = int(max_length or self.model_max_length)
+        rows, types = [], []
+        for i, t in enumerate(texts):
+            a = self._ids(t)
+            if pairs is None:
+                if truncation:
+                    a = a[: max(max_length - 2, 0)]
+                ids = [self.cls_token_id] + a + [self.sep_token_id]
+                tt = [0] * len(ids)
+            else:
+                b = self._ids(pairs[i])
+                if truncation:  # longest-first truncation, like HF's default strategy
+                    budget = max(max_length - 3, 0)
+                    while len(a) + len(b) > budget:
+                        if len(a) > len(b):
+                            a = a[:-1]
+                        else:
+                            b = b[:-1]
+                ids = [self.cls_token_id] + a + [self.sep_token_id] + b + [self.sep_token_id]
+                tt = [0] * (len(a) + 2) + [1] * (len(b) + 1)
+            rows.append(ids)
+            types.append(tt)
+        if padding or return_tensors == "pt":
+            width = max(len(r) for r in rows)
+            if not padding and len({len(r) for r in rows}) > 1:
+                raise ValueError("cannot tensorise ragged rows without padding")
+            mask = [[1] * len(r) + [0] * (width - len(r)) for r in rows]
+            types = [t + [0] * (width - len(t)) for t in types]
+            rows = [r + [self.pad_token_id] * (width - len(r)) for r in rows]
+        else:
+            mask = [[1] * len(r) for r in rows]
+        out = {"input_ids": rows, "attention_mask": mask, "token_type_ids": types}
+        if return_tensors == "pt":
+            out = {k: torch.tensor(v, dtype=torch.long) for k, v in out.items()}
+        return out
+
+
+# --------------------------------------------------------------------------- random models
+_RANDOM_ARCHS = {
+    # arch: (config class name, defaults) — shapes of the models BASELINE.json names
+    "minilm": dict(kind="bert", hidden=384, layers=6, heads=12, inter=1536),          # all-MiniLM-L6 / ms-marco-MiniLM-L6
+    "bert": dict(kind="bert", hidden=768, layers=12, heads=12, inter=3072),
+    "modernbert": dict(kind="modernbert", hidden=768, layers=22, heads=12, inter=1152),  # GTE-ModernColBERT-v1 backbone
+    "xlmr-large": dict(kind="xlm-roberta", hidden=1024, layers=24, heads=16, inter=4096),  # bge-reranker-large
+    "tiny": dict(kind="bert", hidden=64, layers=2, heads=4, inter=128),
+}
+
+
+def _random_config(spec: str, num_labels: Optional[int] = None):
+    import transformers
+    parts = spec.split(":")
+    arch = parts[1] if len(parts) > 1 and parts[1] else "tiny"
+    if arch not in _RANDOM_ARCHS:
+        raise ValueError(f"unknown random architecture {arch!r}; known: {sorted(_RANDOM_ARCHS)}")
+    a = dict(_RANDOM_ARCHS[arch])
+    if len(parts) > 2:
+        a["hidden"] = int(parts[2])
+        a["inter"] = 4 * a["hidden"]
+    if len(parts) > 3:
+        a["layers"] = int(parts[3])
+    if len(parts) > 4:
+        a["heads"] = int(parts[4])
+    kw = dict(hidden_size=a["hidden"], num_hidden_layers=a["layers"], num_attention_heads=a["heads"],
+              intermediate_size=a["inter"], vocab_size=30522, max_position_embeddings=514)
+    if num_labels is not None:
+        kw["num_labels"] = num_labels
+    if a["kind"] == "bert":
+        return transformers.BertConfig(**kw)
+    if a["kind"] == "xlm-roberta":
+        return transformers.XLMRobertaConfig(**kw, pad_token_id=0, type_vocab_size=2)
+    if a["kind"] == "modernbert":
+        kw.pop("max_position_embeddings")
+        return transformers.ModernBertConfig(**kw, max_position_embeddings=8192, pad_token_id=0,
+                                             cls_token_id=101, sep_token_id=102, bos_token_id=101,
+                                             eos_token_id=102)
+    raise ValueError(a["kind"])
+
+
+def load_backbone(model_name: str, cache_dir: str = "./models", head: str = "base",
+                  num_labels: int = 1, seed: int = 0):
+    """Returns (tokenizer, model, source_dir_or_None).  head: 'base' (AutoModel) or
+    'seqcls' (AutoModelForSequenceClassification)."""
+    import transformers
+    if model_name.startswith("random:"):
+        cfg = _random_config(model_name, num_labels if head == "seqcls" else None)
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        try:
+            model = (transformers.AutoModelForSequenceClassification.from_config(cfg) if head == "seqcls"
+                     else transformers.AutoModel.from_config(cfg))
+        finally:
+            torch.random.set_rng_state(gen_state)
+        return HashTokenizer(cfg.vocab_size), model, None
+    src = local_model_dir(model_name, cache_dir) or model_name
+    tok = transformers.AutoTokenizer.from_pretrained(src, cache_dir=cache_dir)
+    cls = transformers.AutoModelForSequenceClassification if head == "seqcls" else transformers.AutoModel
+    model = cls.from_pretrained(src, cache_dir=cache_dir)
+    return tok, model, (src if os.path.isdir(src) else None)
+
+
+def _autocast(device: str, enabled: bool, dtype=torch.bfloat16):
+    if enabled and str(device).startswith("cuda"):
+        return torch.autocast("cuda", dtype=dtype)
+    import contextlib
+    return contextlib.nullcontext()
+
+
+# --------------------------------------------------------------------------- bi-encoder
+class SentenceEncoder:
+    """Stand-in for sentence_transformers.SentenceTransformer (see module docstring)."""
+
+    def __init__(self, model_name: str, device: str = "auto", cache_folder: str = "./models",
+                 max_seq_length: Optional[int] = None, amp_dtype=torch.bfloat16, seed: int = 0):
+        self.model_name = model_name
+        self.device = resolve_device(device)
+        self.tokenizer, self.model, src = load_backbone(model_name, cache_folder, "base", seed=seed)
+        self.model.to(self.device).eval()
+        self.amp_dtype = amp_dtype
+        self.pooling_mode = "mean"
+        self.normalize = False
+        self.dense: List[torch.nn.Module] = []
+        self.max_seq_length = int(max_seq_length or min(getattr(self.tokenizer, "model_max_length", 512), 512))
+        if src:
+            self._read_st_modules(src)
+
+    # sentence-transformers directory layout: modules.json + N_<Module>/config.json
+    def _read_st_modules(self, src: str) -> None:
+        mj = os.path.join(src, "modules.json")
+        if not os.path.exists(mj):
+            return
+        for mod in json.load(open(mj)):
+            path, typ = os.path.join(src, mod.get("path", "")), mod.get("type", "")
+            cfgp = os.path.join(path, "config.json")
+            if typ.endswith("Pooling") and os.path.exists(cfgp):
+                c = json.load(open(cfgp))
+                if c.get("pooling_mode_cls_token"):
+                    self.pooling_mode = "cls"
+                elif c.get("pooling_mode_max_tokens"):
+                    self.pooling_mode = "max"
+                else:
+                    self.pooling_mode = "mean"
+            elif typ.endswith("Dense") and os.path.exists(cfgp):
+                c = json.load(open(cfgp))
+                lin = torch.nn.Linear(c["in_features"], c["out_features"], bias=c.get("bias", True))
+                wp = os.path.join(path, "model.safetensors")
+                if os.path.exists(wp):
+                    from safetensors.torch import load_file
+                    sd = load_file(wp)
+                    lin.load_state_dict({k.replace("linear.", ""): v for k, v in sd.items()})
+                act = c.get("activation_function", "torch.nn.modules.linear.Identity")
+                seq = [lin] + ([torch.nn.Tanh()] if act.endswith("Tanh") else [])
+                self.dense.append(torch.nn.Sequential(*seq).to(self.device).eval())
+            elif typ.endswith("Normalize"):
+                self.normalize = True
+            elif typ.endswith("Transformer"):
+                sc = os.path.join(path, "sentence_bert_config.json")
+                if os.path.exists(sc):
+                    self.max_seq_length = int(json.load(open(sc)).get("max_seq_length", self.max_seq_length))
+
+    def get_sentence_embedding_dimension(self) -> int:
+        if self.dense:
+            return int(self.dense[-1][0].out_features)
+        return int(self.model.config.hidden_size)
+
+    def _pool(self, hidden: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        if self.pooling_mode == "cls":
+            return hidden[:, 0]
+        m = mask.unsqueeze(-1).to(hidden.dtype)
+        if self.pooling_mode == "max":
+            return hidden.masked_fill(m == 0, -1e9).max(dim=1).values
+        return (hidden * m).sum(1) / m.sum(1).clamp(min=1e-9)
+
+    @torch.no_grad()
+    def encode(self, sentences: Union[str, Sequence[str]], batch_size: int = 32,
+               convert_to_numpy: bool = True, convert_to_tensor: bool = False,
+               show_progress_bar: bool = False, normalize_embeddings: bool = False, **_):
+        single = isinstance(sentences, str)
+        texts = [sentences] if single else list(sentences)
+        order = np.argsort([-len(t) for t in texts], kind="stable")  # length-sorted batches
+        out: List[Optional[torch.Tensor]] = [None] * len(texts)
+        use_amp = torch.is_autocast_enabled() or False
+        for s in range(0, len(texts), batch_size):
+            idx = order[s:s + batch_size]
+            enc = self.tokenizer([texts[i] for i in idx], truncation=True, padding=True,
+                                 max_length=self.max_seq_length, return_tensors="pt")
+            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
+                enc.pop("token_type_ids")
+            hidden = self.model(**enc).last_hidden_state
+            emb = self._pool(hidden.float(), enc["attention_mask"])
+            for d in self.dense:
+                emb = d(emb)
+            if self.normalize or normalize_embeddings:
+                emb = F.normalize(emb, p=2, dim=1)
+            for j, i in enumerate(idx):
+                out[i] = emb[j]
+        del use_amp
+        res = torch.stack(out).float() if out else torch.zeros((0, self.get_sentence_embedding_dimension()))
+        if single:
+            res = res[0]
+        if convert_to_tensor:
+            return res
+        return res.cpu().numpy() if convert_to_numpy else list(res)
+
+
+# --------------------------------------------------------------------------- cross-encoder
+class CrossEncoderModel:
+    """Stand-in for sentence_transformers.CrossEncoder (see module docstring)."""
+
+    def __init__(self, model_name: str, device: str = "auto", max_length: int = 256,
+                 cache_folder: str = "./models", amp_dtype=torch.bfloat16, use_amp: bool = True,
+                 seed: int = 0):
+        self.device = resolve_device(device)
+        self.tokenizer, self.model, _ = load_backbone(model_name, cache_folder, "seqcls", num_labels=1,
+                                                      seed=seed)
+        self.model.to(self.device).eval()
+        self.max_length = int(max_length)
+        self.num_labels = int(getattr(self.model.config, "num_labels", 1))
+        act = getattr(self.model.config, "sbert_ce_default_activation_function", None)
+        if act is not None:
+            self.activation = "identity" if str(act).endswith("Identity") else "sigmoid"
+        else:
+            self.activation = "sigmoid" if self.num_labels == 1 else "identity"
+        self.amp_dtype = amp_dtype
+        self.use_amp = use_amp
+
+    @torch.no_grad()
+    def logits(self, pairs: Sequence[Sequence[str]], batch_size: int = 32) -> torch.Tensor:
+        """Raw logits [P, num_labels] (float32, on the model's device), batched in
+        length-sorted order like CrossEncoder.predict."""
+        pairs = [list(p) for p in pairs]
+        order = np.argsort([-(len(p[0]) + len(p[1])) for p in pairs], kind="stable")
+        out: List[Optional[torch.Tensor]] = [None] * len(pairs)
+        for s in range(0, len(pairs), batch_size):
+            idx = order[s:s + batch_size]
+            enc = self.tokenizer([pairs[i][0] for i in idx], [pairs[i][1] for i in idx], truncation=True,
+                                 padding=True, max_length=self.max_length, return_tensors="pt")
+            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            with _autocast(self.device, self.use_amp, self.amp_dtype):
+                lg = self.model(**enc).logits.float()
+            for j, i in enumerate(idx):
+                out[i] = lg[j]
+        return torch.stack(out) if out else torch.zeros((0, self.num_labels), device=self.device)
+
+    def predict(self, sentences: Sequence[Sequence[str]], batch_size: int = 32,
+                show_progress_bar: bool = False, **_) -> np.ndarray:
+        lg = self.logits(sentences, batch_size=batch_size)
+        if self.activation == "sigmoid":
+            lg = torch.sigmoid(lg)
+        if self.num_labels == 1:
+            lg = lg.squeeze(-1)
+        return lg.cpu().numpy().astype(np.float32)
