@@ -1,0 +1,314 @@
+"""RetrievalPipeline — the three-stage orchestrator, API-compatible with the
+reference's src/retrieval_pipeline.py.
+
+Kept verbatim: ``PipelineConfig`` field names and defaults
+(reference :52-87), ``RetrievalPipeline(config_path=None, config=None)``, lazy
+``initialize_stages`` (:238-290), ``add_documents`` (:292-321), ``search`` with its
+result keys ``query / results / stage1_results / stage2_results / timing /
+performance_stats`` and the early returns when a stage yields nothing (:323-424),
+``batch_search``, ``save_index`` / ``load_index``, ``get_pipeline_info``,
+``export_config``, the running-mean ``performance_stats`` (:567-606).
+
+MI355X-side differences: stage 1 is the exact HIP index, stage 2 one MaxSim
+kernel launch per query, no ``torch.cuda.empty_cache()`` per query, and
+``search_many`` pushes a whole query batch through one stage-1 sweep.
+Additive config fields carry a default so reference YAML files still load.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from dataclasses import asdict, dataclass, fields
+from typing import Any, Dict, List, Optional
+
+import yaml
+
+from .stage1_retriever import Stage1Config, Stage1Retriever
+from .stage2_rescorer import ColBERTScorer, Stage2Config
+from .stage3_reranker import AdaptiveCrossEncoderReranker, Stage3Config
+
+
+@dataclass
+class PipelineConfig:
+    """All knobs of the three-stage pipeline (reference src/retrieval_pipeline.py:15-87)."""
+    # Stage 1
+    stage1_model: str = "google/embeddinggemma-300m"
+    stage1_top_k: int = 500
+    stage1_batch_size: int = 32
+    stage1_enable_bm25: bool = True
+    stage1_bm25_top_k: int = 300
+    stage1_fusion_method: str = "rrf"
+    stage1_use_fp16: bool = True
+    # Stage 2
+    stage2_model: str = "lightonai/GTE-ModernColBERT-v1"
+    stage2_top_k: int = 100
+    stage2_batch_size: int = 16
+    stage2_max_seq_length: int = 192
+    stage2_use_fp16: bool = True
+    stage2_scoring_method: str = "maxsim"
+    # Stage 3
+    stage3_model: str = "cross-encoder/ms-marco-MiniLM-L6-v2"
+    stage3_top_k: int = 20
+    stage3_batch_size: int = 32
+    stage3_max_length: int = 256
+    stage3_use_fp16: bool = True
+    # General
+    device: str = "auto"
+    cache_dir: str = "./models"
+    index_dir: str = "./faiss_index"
+    log_level: str = "INFO"
+    log_file: str = "retrieval_pipeline.log"
+    enable_timing: bool = True
+    save_intermediate_results: bool = False
+    auto_cleanup: bool = True
+    max_memory_usage_gb: float = 4.0
+    # ---- additive (MI355X) ----
+    stage1_index_dtype: str = "f32"          # corpus storage on the GPU: f32 | f16 | bf16
+    stage2_cache_document_embeddings: bool = False
+
+
+# (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
+_YAML_MAP = {
+    ("stage1", "model"): "stage1_model", ("stage1", "top_k"): "stage1_top_k",
+    ("stage1", "batch_size"): "stage1_batch_size", ("stage1", "enable_bm25"): "stage1_enable_bm25",
+    ("stage1", "bm25_top_k"): "stage1_bm25_top_k", ("stage1", "fusion_method"): "stage1_fusion_method",
+    ("stage1", "use_fp16"): "stage1_use_fp16", ("stage1", "index_dtype"): "stage1_index_dtype",
+    ("stage2", "model"): "stage2_model", ("stage2", "top_k"): "stage2_top_k",
+    ("stage2", "batch_size"): "stage2_batch_size", ("stage2", "max_seq_length"): "stage2_max_seq_length",
+    ("stage2", "use_fp16"): "stage2_use_fp16", ("stage2", "scoring_method"): "stage2_scoring_method",
+    ("stage3", "model"): "stage3_model", ("stage3", "top_k"): "stage3_top_k",
+    ("stage3", "batch_size"): "stage3_batch_size", ("stage3", "max_length"): "stage3_max_length",
+    ("stage3", "use_fp16"): "stage3_use_fp16",
+}
+_GENERAL_KEYS = ("device", "cache_dir", "index_dir", "log_level", "log_file", "enable_timing",
+                 "save_intermediate_results", "auto_cleanup", "max_memory_usage_gb")
+
+
+class RetrievalPipeline:
+    """Stage 1 candidate generation -> stage 2 MaxSim rescoring -> stage 3 cross-encoder."""
+
+    def __init__(self, config_path: Optional[str] = None, config: Optional[PipelineConfig] = None):
+        self.logger = logging.getLogger(__name__)
+        if config_path:
+            self.config = self._load_config(config_path)
+        elif config:
+            self.config = config
+        else:
+            self.config = PipelineConfig()
+        self._setup_logging()
+        self.stage1: Optional[Stage1Retriever] = None
+        self.stage2: Optional[ColBERTScorer] = None
+        self.stage3: Optional[AdaptiveCrossEncoderReranker] = None
+        self.performance_stats: Dict[str, Any] = {
+            "total_queries": 0, "avg_stage1_time": 0.0, "avg_stage2_time": 0.0,
+            "avg_stage3_time": 0.0, "avg_total_time": 0.0, "stage_time_history": []}
+        self.logger.info("RetrievalPipeline initialized")
+
+    # -- configuration -------------------------------------------------------
+    def _load_config(self, config_path: str) -> PipelineConfig:
+        """YAML with a top-level ``pipeline:`` mapping; nested stage sections as in the
+        reference, or the flat field names that ``export_config`` writes."""
+        try:
+            with open(config_path, "r") as f:
+                data = yaml.safe_load(f) or {}
+            pd = data.get("pipeline", {}) or {}
+            kw: Dict[str, Any] = {}
+            names = {f.name for f in fields(PipelineConfig)}
+            for k, v in pd.items():
+                if k in names and not isinstance(v, dict):
+                    kw[k] = v
+            for (section, key), field_name in _YAML_MAP.items():
+                sec = pd.get(section)
+                if isinstance(sec, dict) and key in sec:
+                    kw[field_name] = sec[key]
+            for k in _GENERAL_KEYS:
+                if k in pd:
+                    kw[k] = pd[k]
+            return PipelineConfig(**kw)
+        except Exception as e:  # reference :219-221: fall back to defaults
+            self.logger.error(f"Error loading config: {e}")
+            return PipelineConfig()
+
+    def _setup_logging(self) -> None:
+        level = getattr(logging, str(self.config.log_level).upper(), logging.INFO)
+        handlers: List[logging.Handler] = [logging.StreamHandler()]
+        try:
+            handlers.insert(0, logging.FileHandler(self.config.log_file))
+        except OSError:
+            pass
+        logging.basicConfig(level=level, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s",
+                            handlers=handlers)
+
+    def initialize_stages(self) -> None:
+        self.logger.info("Initializing pipeline stages...")
+        c = self.config
+        try:
+            self.stage1 = Stage1Retriever(Stage1Config(
+                model_name=c.stage1_model, device=c.device, cache_dir=c.cache_dir, index_dir=c.index_dir,
+                top_k_candidates=c.stage1_top_k, batch_size=c.stage1_batch_size,
+                enable_bm25=c.stage1_enable_bm25, bm25_top_k=c.stage1_bm25_top_k,
+                fusion_method=c.stage1_fusion_method, use_fp16=c.stage1_use_fp16,
+                index_dtype=c.stage1_index_dtype))
+            self.logger.info("Stage 1 initialized")
+            self.stage2 = ColBERTScorer(Stage2Config(
+                model_name=c.stage2_model, device=c.device, cache_dir=c.cache_dir,
+                max_seq_length=c.stage2_max_seq_length, batch_size=c.stage2_batch_size,
+                top_k_candidates=c.stage2_top_k, use_fp16=c.stage2_use_fp16,
+                scoring_method=c.stage2_scoring_method,
+                cache_document_embeddings=c.stage2_cache_document_embeddings))
+            self.logger.info("Stage 2 initialized")
+            self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
+                model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
+                max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
+                top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16))
+            self.logger.info("Stage 3 initialized")
+        except Exception as e:
+            self.logger.error(f"Error initializing pipeline stages: {e}")
+            raise
+
+    # -- indexing --------------------------------------------------------------
+    def add_documents(self, documents: List[str], metadata: Optional[List[Dict[str, Any]]] = None):
+        if not self.stage1:
+            self.initialize_stages()
+        self.logger.info(f"Adding {len(documents)} documents to pipeline")
+        try:
+            self.stage1.add_documents(documents, metadata)
+        except Exception as e:
+            self.logger.error(f"Error adding documents: {e}")
+            raise
+
+    # -- search ----------------------------------------------------------------
+    def _now(self) -> Optional[float]:
+        return time.time() if self.config.enable_timing else None
+
+    def _get_timing(self, enable_timing: bool) -> Optional[float]:
+        return time.time() if enable_timing else None
+
+    def _calculate_timing(self, total_start, stage1_time, stage2_time, stage3_time) -> Dict[str, float]:
+        if not self.config.enable_timing:
+            return {}
+        total = time.time() - total_start if total_start else None
+        return {"stage1_time": stage1_time or 0.0, "stage2_time": stage2_time or 0.0,
+                "stage3_time": stage3_time or 0.0, "total_time": total or 0.0}
+
+    def _run_later_stages(self, query: str, top_k: int, stage1_results, total_start, stage1_time):
+        if not stage1_results:
+            return {"query": query, "results": [], "stage1_results": [], "stage2_results": [],
+                    "timing": self._calculate_timing(total_start, stage1_time, None, None),
+                    "performance_stats": self.performance_stats}
+        t = self._now()
+        stage2_results = self.stage2.rescore_candidates(query, stage1_results)
+        stage2_time = time.time() - t if t else None
+        if not stage2_results:
+            return {"query": query, "results": [], "stage1_results": stage1_results, "stage2_results": [],
+                    "timing": self._calculate_timing(total_start, stage1_time, stage2_time, None),
+                    "performance_stats": self.performance_stats}
+        t = self._now()
+        final = self.stage3.rerank(query, stage2_results)
+        stage3_time = time.time() - t if t else None
+        final = final[:top_k]
+        total_time = time.time() - total_start if total_start else None
+        if self.config.enable_timing:
+            self._update_performance_stats(stage1_time, stage2_time, stage3_time, total_time)
+        keep = self.config.save_intermediate_results
+        result = {"query": query, "results": final,
+                  "stage1_results": stage1_results if keep else [],
+                  "stage2_results": stage2_results if keep else [],
+                  "timing": self._calculate_timing(total_start, stage1_time, stage2_time, stage3_time),
+                  "performance_stats": self.performance_stats.copy()}
+        if self.config.auto_cleanup:
+            self._cleanup_memory()
+        return result
+
+    def search(self, query: str, top_k: Optional[int] = None) -> Dict[str, Any]:
+        if not self.stage1 or not self.stage2 or not self.stage3:
+            self.initialize_stages()
+        top_k = top_k or self.config.stage3_top_k
+        total_start = self._now()
+        try:
+            t = self._now()
+            stage1_results = self.stage1.search(query, self.config.stage1_top_k)
+            stage1_time = time.time() - t if t else None
+            return self._run_later_stages(query, top_k, stage1_results, total_start, stage1_time)
+        except Exception as e:
+            self.logger.error(f"Error during search: {e}")
+            raise
+
+    def batch_search(self, queries: List[str], top_k: Optional[int] = None) -> List[Dict[str, Any]]:
+        """Sequential, like the reference (:444-448); see search_many for the batched form."""
+        return [self.search(q, top_k) for q in queries]
+
+    def search_many(self, queries: List[str], top_k: Optional[int] = None) -> List[Dict[str, Any]]:
+        """Same results as batch_search; stage 1 runs once for the whole batch (one
+        encoder pass, one sweep of the corpus for up to 64 queries at a time)."""
+        if not self.stage1 or not self.stage2 or not self.stage3:
+            self.initialize_stages()
+        top_k = top_k or self.config.stage3_top_k
+        if not queries:
+            return []
+        t0 = self._now()
+        per_query = self.stage1.search_many(queries, self.config.stage1_top_k)
+        share = (time.time() - t0) / len(queries) if t0 else None
+        out = []
+        for q, s1 in zip(queries, per_query):
+            out.append(self._run_later_stages(q, top_k, s1, self._now(), share))
+        return out
+
+    # -- persistence -------------------------------------------------------------
+    def save_index(self, index_path: Optional[str] = None):
+        if not self.stage1:
+            raise ValueError("Pipeline not initialized")
+        if index_path is None:
+            index_path = os.path.join(self.config.index_dir, "pipeline_index.pkl")
+        self.stage1.save_index(index_path)
+        self.logger.info(f"Pipeline index saved to {index_path}")
+
+    def load_index(self, index_path: Optional[str] = None):
+        if not self.stage1:
+            self.initialize_stages()
+        if index_path is None:
+            index_path = os.path.join(self.config.index_dir, "pipeline_index.pkl")
+        self.stage1.load_index(index_path)
+        self.logger.info(f"Pipeline index loaded from {index_path}")
+
+    # -- introspection -----------------------------------------------------------
+    def get_pipeline_info(self) -> Dict[str, Any]:
+        info = {"config": asdict(self.config),
+                "stages_initialized": {"stage1": self.stage1 is not None, "stage2": self.stage2 is not None,
+                                       "stage3": self.stage3 is not None},
+                "performance_stats": self.performance_stats}
+        if self.stage1:
+            info["stage1_stats"] = self.stage1.get_stats()
+        if self.stage2:
+            info["stage2_info"] = self.stage2.get_model_info()
+        if self.stage3:
+            info["stage3_info"] = self.stage3.get_model_info()
+        return info
+
+    def _update_performance_stats(self, stage1_time, stage2_time, stage3_time, total_time):
+        """Cumulative mean with alpha = 1/n and a 100-entry history (reference :567-606)."""
+        ps = self.performance_stats
+        ps["total_queries"] += 1
+        alpha = 1.0 / ps["total_queries"]
+        for key, val in (("avg_stage1_time", stage1_time), ("avg_stage2_time", stage2_time),
+                         ("avg_stage3_time", stage3_time), ("avg_total_time", total_time)):
+            ps[key] = (1 - alpha) * ps[key] + alpha * val
+        ps["stage_time_history"].append({"stage1": stage1_time, "stage2": stage2_time,
+                                         "stage3": stage3_time, "total": total_time})
+        if len(ps["stage_time_history"]) > 100:
+            ps["stage_time_history"] = ps["stage_time_history"][-100:]
+
+    def _cleanup_memory(self):
+        try:
+            if self.stage2:
+                self.stage2.clear_gpu_memory()
+            if self.stage3:
+                self.stage3.clear_gpu_memory()
+        except Exception as e:
+            self.logger.warning(f"Error during memory cleanup: {e}")
+
+    def export_config(self, config_path: str):
+        with open(config_path, "w") as f:
+            yaml.dump({"pipeline": asdict(self.config)}, f, default_flow_style=False)
+        self.logger.info(f"Configuration exported to {config_path}")

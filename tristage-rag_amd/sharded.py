@@ -102,8 +102,9 @@ class ShardedFlatIPIndex:
         B, k = D.shape
         packed = torch.cat([D.contiguous().view(torch.uint8).reshape(-1),
                             I.contiguous().view(torch.uint8).reshape(-1)])
-        out = torch.empty((self.world_size, packed.numel()), dtype=torch.uint8, device=packed.device)
-        self._dist.all_gather_into_tensor(out, packed, group=self.group)
+        flat = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8, device=packed.device)
+        self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
+        out = flat.view(self.world_size, packed.numel())
         ns = B * k * 4
         Dg = out[:, :ns].contiguous().view(torch.float32).reshape(self.world_size, B, k)
         Ig = out[:, ns:].contiguous().view(torch.int64).reshape(self.world_size, B, k)

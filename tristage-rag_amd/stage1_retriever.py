@@ -1,0 +1,341 @@
+"""Stage 1: dense candidate generation on the MI355X index (+ optional BM25 fusion).
+
+Mirror of reference src/stage1_retriever.py: same class names, config fields,
+attributes callers reach into (``documents``, ``doc_metadata``, ``faiss_index``,
+``bm25_index``, ``model``) and result-dict schema (:403-416).
+What differs underneath:
+
+* ``faiss_index`` is a tristage_rag_amd.index.FlatIPIndex (HIP, exact inner
+  product).  The reference switches to IndexIVFFlat(nlist=100, nprobe=10) when the
+  first add has >1000 rows (:262-273), an approximation of the exact result this
+  index returns; exact search is kept for every size.
+* row normalisation ``x / (|x| + 1e-8)`` (:285-288) runs on the GPU inside
+  ``add`` when the embeddings are already on the device.
+* ``search_many`` batches queries through one index call (the reference loops one
+  query at a time, src/retrieval_pipeline.py:444-448).
+* BM25 keeps an inverted index instead of per-document dict scans; scores, tie
+  order and the fusion arithmetic are the reference's (:35-112, :326-366).  One
+  deliberate difference: ``fit`` rebuilds its statistics from scratch, where the
+  reference appends to ``doc_freqs`` on every re-fit (:73-74) and misaligns
+  document ids after a second ``add_documents``.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import math
+import os
+import re
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass
+class Stage1Config:
+    model_name: str = "google/embeddinggemma-300m"
+    device: str = "auto"
+    cache_dir: str = "./models"
+    index_dir: str = "./faiss_index"
+    top_k_candidates: int = 500
+    batch_size: int = 32
+    max_text_length: int = 512
+    enable_bm25: bool = True
+    bm25_top_k: int = 300
+    fusion_method: str = "rrf"  # "rrf" (Reciprocal Rank Fusion) or "weighted"
+    rrf_k: int = 60
+    dense_weight: float = 0.7
+    bm25_weight: float = 0.3
+    use_fp16: bool = True
+    nlist: int = 100  # kept for config compatibility; the index is exact
+    nprobe: int = 10
+    # additive knobs (not in the reference)
+    index_dtype: str = "f32"   # storage dtype of the corpus matrix: f32 | f16 | bf16
+    gpu_index_device: int = 0
+
+
+class BM25Index:
+    """BM25 (k1=1.2, b=0.75) with the reference's tokenizer and idf
+    (reference src/stage1_retriever.py:35-112), over an inverted index."""
+
+    def __init__(self, k1: float = 1.2, b: float = 0.75):
+        self.k1 = k1
+        self.b = b
+        self.doc_freqs: List[Dict[str, int]] = []
+        self.idf: Dict[str, float] = {}
+        self.doc_lens: List[int] = []
+        self.avg_doc_len = 0
+        self.corpus_size = 0
+        self.vocabulary = set()
+        self.documents: List[str] = []
+        self._postings: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+        self._len_norm = np.zeros(0)
+
+    def tokenize(self, text: str) -> List[str]:
+        text = text.lower()
+        text = re.sub(r"[^a-z0-9\s]", " ", text)
+        return text.split()
+
+    def fit(self, documents: Sequence[str]) -> None:
+        self.documents = list(documents)
+        self.corpus_size = len(self.documents)
+        self.doc_freqs, self.doc_lens, self.idf = [], [], {}
+        self.vocabulary = set()
+        post_d: Dict[str, List[int]] = defaultdict(list)
+        post_tf: Dict[str, List[int]] = defaultdict(list)
+        for i, doc in enumerate(self.documents):
+            tf: Dict[str, int] = defaultdict(int)
+            toks = self.tokenize(doc)
+            for t in toks:
+                tf[t] += 1
+            self.doc_freqs.append(tf)
+            self.doc_lens.append(len(toks))
+            for t, c in tf.items():
+                post_d[t].append(i)
+                post_tf[t].append(c)
+        self.vocabulary = set(post_d)
+        self.avg_doc_len = sum(self.doc_lens) / self.corpus_size if self.corpus_size > 0 else 0
+        n = self.corpus_size
+        for t, ds in post_d.items():
+            df = len(ds)
+            self.idf[t] = math.log((n - df + 0.5) / (df + 0.5) + 1.0)
+        self._postings = {t: (np.asarray(post_d[t], dtype=np.int64), np.asarray(post_tf[t], dtype=np.float64))
+                          for t in post_d}
+        lens = np.asarray(self.doc_lens, dtype=np.float64)
+        self._len_norm = (self.k1 * (1 - self.b + self.b * lens / self.avg_doc_len)
+                          if self.avg_doc_len else np.zeros_like(lens))
+
+    def score(self, query: str, doc_idx: int) -> float:
+        if doc_idx >= len(self.doc_freqs):
+            return 0.0
+        f, dl, s = self.doc_freqs[doc_idx], self.doc_lens[doc_idx], 0.0
+        for tok in self.tokenize(query):
+            if tok in f and tok in self.idf:
+                tf = f[tok]
+                s += self.idf[tok] * ((tf * (self.k1 + 1)) /
+                                      (tf + self.k1 * (1 - self.b + self.b * dl / self.avg_doc_len)))
+        return s
+
+    def scores(self, query: str) -> np.ndarray:
+        """Scores of every document, accumulated term by term in query order
+        (the same order of float additions as the per-document loop)."""
+        acc = np.zeros(self.corpus_size, dtype=np.float64)
+        for tok in self.tokenize(query):
+            p = self._postings.get(tok)
+            if p is None:
+                continue
+            ds, tf = p
+            acc[ds] += self.idf[tok] * ((tf * (self.k1 + 1)) / (tf + self._len_norm[ds]))
+        return acc
+
+    def search(self, query: str, top_k: int = 10) -> List[Tuple[int, float]]:
+        s = self.scores(query)
+        order = np.argsort(-s, kind="stable")[:top_k]  # ties keep ascending doc order
+        return [(int(i), float(s[i])) for i in order]
+
+
+class Stage1Retriever:
+    """Stage 1: dense embeddings + exact MI355X index + optional BM25 fusion."""
+
+    def __init__(self, config: Stage1Config, model: Any = None,
+                 index_factory: Optional[Callable[[int], Any]] = None):
+        self.config = config
+        self.logger = logging.getLogger(__name__)
+        self.model = model
+        self.embedding_dim: Optional[int] = None
+        self.faiss_index = None
+        self.bm25_index: Optional[BM25Index] = None
+        self.documents: List[str] = []
+        self.doc_metadata: List[Dict[str, Any]] = []
+        self._index_factory = index_factory
+        os.makedirs(self.config.cache_dir, exist_ok=True)
+        os.makedirs(self.config.index_dir, exist_ok=True)
+        self._load_model()
+
+    # -- model -------------------------------------------------------------
+    def _load_model(self) -> None:
+        if self.model is None:
+            from .encoders import SentenceEncoder
+            self.logger.info(f"Loading Stage 1 model: {self.config.model_name}")
+            self.model = SentenceEncoder(self.config.model_name, device=self.config.device,
+                                         cache_folder=self.config.cache_dir)
+        if hasattr(self.model, "get_sentence_embedding_dimension"):
+            self.embedding_dim = self.model.get_sentence_embedding_dimension()
+        else:
+            self.embedding_dim = int(np.asarray(self.model.encode("sample text", convert_to_numpy=True)).shape[0])
+        self.logger.info(f"Model loaded successfully. Embedding dimension: {self.embedding_dim}")
+
+    def _encode_batch(self, texts: List[str]) -> np.ndarray:
+        """reference :230-254 — float32 [n, d] embeddings (AMP on the GPU when use_fp16)."""
+        import torch
+        dev = str(getattr(self.model, "device", "cpu"))
+        if self.config.use_fp16 and dev.startswith("cuda"):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                emb = self.model.encode(texts, batch_size=self.config.batch_size, convert_to_numpy=True,
+                                        show_progress_bar=False)
+        else:
+            emb = self.model.encode(texts, batch_size=self.config.batch_size, convert_to_numpy=True,
+                                    show_progress_bar=False)
+        return np.asarray(emb).astype(np.float32)
+
+    def _normalize_embeddings(self, embeddings: np.ndarray) -> np.ndarray:
+        """reference :285-288"""
+        norms = np.linalg.norm(embeddings, axis=1, keepdims=True)
+        return embeddings / (norms + 1e-8)
+
+    # -- index -------------------------------------------------------------
+    def _create_faiss_index(self, embeddings: np.ndarray) -> None:
+        d = int(embeddings.shape[1])
+        if self._index_factory is not None:
+            self.faiss_index = self._index_factory(d)
+        else:
+            from .index import FlatIPIndex  # raises without libtristage.so / a GPU: no CPU fallback
+            self.faiss_index = FlatIPIndex(d, dtype=self.config.index_dtype,
+                                           device=self.config.gpu_index_device)
+        self.faiss_index.add(embeddings)
+        self.logger.info(f"Index created with {len(embeddings)} vectors (exact inner product)")
+
+    def add_documents(self, documents: List[str], metadata: Optional[List[Dict[str, Any]]] = None):
+        if not documents:
+            return
+        self.logger.info(f"Adding {len(documents)} documents to Stage 1 index")
+        self.documents.extend(documents)
+        if metadata is None:
+            metadata = [{}] * len(documents)  # one shared dict, as in the reference (:302)
+        self.doc_metadata.extend(metadata)
+        embeddings = self._normalize_embeddings(self._encode_batch(list(documents)))
+        if self.faiss_index is None:
+            self._create_faiss_index(embeddings)
+        else:
+            self.faiss_index.add(embeddings)
+        if self.config.enable_bm25:
+            if self.bm25_index is None:
+                self.bm25_index = BM25Index()
+            self.bm25_index.fit(self.documents)
+        self.logger.info(f"Documents added successfully. Total documents: {len(self.documents)}")
+
+    # -- fusion ------------------------------------------------------------
+    def _reciprocal_rank_fusion(self, dense_results, bm25_results):
+        """reference :326-343"""
+        scores: Dict[int, float] = defaultdict(float)
+        for rank, (doc_idx, _) in enumerate(dense_results):
+            scores[doc_idx] += 1.0 / (self.config.rrf_k + rank + 1)
+        for rank, (doc_idx, _) in enumerate(bm25_results):
+            scores[doc_idx] += 1.0 / (self.config.rrf_k + rank + 1)
+        fused = [(i, s) for i, s in scores.items()]
+        fused.sort(key=lambda x: x[1], reverse=True)
+        return fused
+
+    def _weighted_fusion(self, dense_results, bm25_results):
+        """reference :345-366"""
+        scores: Dict[int, float] = defaultdict(float)
+        if dense_results:
+            mx = max(s for _, s in dense_results)
+            for i, s in dense_results:
+                scores[i] += self.config.dense_weight * (s / mx)
+        if bm25_results:
+            mx = max(s for _, s in bm25_results)
+            for i, s in bm25_results:
+                scores[i] += self.config.bm25_weight * (s / mx)
+        fused = [(i, s) for i, s in scores.items()]
+        fused.sort(key=lambda x: x[1], reverse=True)
+        return fused
+
+    # -- search ------------------------------------------------------------
+    def _finish(self, query: str, dense_results: List[Tuple[int, float]], top_k: int) -> List[Dict[str, Any]]:
+        bm25_results: List[Tuple[int, float]] = []
+        if self.config.enable_bm25 and self.bm25_index is not None:
+            bm25_results = self.bm25_index.search(query, self.config.bm25_top_k)
+        if self.config.enable_bm25 and bm25_results:
+            if self.config.fusion_method == "rrf":
+                fused = self._reciprocal_rank_fusion(dense_results, bm25_results)
+            else:
+                fused = self._weighted_fusion(dense_results, bm25_results)
+            final = fused[:top_k]
+        else:
+            final = dense_results[:top_k]
+        results = []
+        for doc_idx, score in final:
+            if doc_idx < len(self.documents):
+                results.append({"doc_id": doc_idx, "document": self.documents[doc_idx], "score": score,
+                                "stage1_score": score, "metadata": self.doc_metadata[doc_idx],
+                                "stage": "stage1"})
+        return results
+
+    def search(self, query: str, top_k: Optional[int] = None) -> List[Dict[str, Any]]:
+        if self.faiss_index is None:
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        top_k = top_k or self.config.top_k_candidates
+        q = self._normalize_embeddings(self._encode_batch([query]))
+        scores, ids = self.faiss_index.search(q, top_k)
+        dense = [(int(i), float(s)) for i, s in zip(ids[0], scores[0]) if i >= 0]
+        results = self._finish(query, dense, top_k)
+        self.logger.info(f"Stage 1 search completed. Found {len(results)} candidates")
+        return results
+
+    def search_many(self, queries: Sequence[str], top_k: Optional[int] = None) -> List[List[Dict[str, Any]]]:
+        """All queries through ONE encoder pass and ONE index call (64 queries share a
+        single sweep over the corpus on the GPU)."""
+        if self.faiss_index is None:
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        top_k = top_k or self.config.top_k_candidates
+        if not queries:
+            return []
+        q = self._normalize_embeddings(self._encode_batch(list(queries)))
+        scores, ids = self.faiss_index.search(q, top_k)
+        out = []
+        for qi, query in enumerate(queries):
+            dense = [(int(i), float(s)) for i, s in zip(ids[qi], scores[qi]) if i >= 0]
+            out.append(self._finish(query, dense, top_k))
+        return out
+
+    # -- persistence (reference :421-465; raw matrix + JSON instead of pickle + faiss file)
+    def save_index(self, index_path: Optional[str] = None):
+        if index_path is None:
+            index_path = os.path.join(self.config.index_dir, "stage1_index.pkl")
+        base = os.path.splitext(index_path)[0]
+        os.makedirs(os.path.dirname(os.path.abspath(index_path)), exist_ok=True)
+        manifest = {"format": "tristage-rag_amd/1", "documents": self.documents,
+                    "doc_metadata": self.doc_metadata, "config": dict(self.config.__dict__),
+                    "ntotal": 0, "dim": self.embedding_dim, "matrix": None}
+        if self.faiss_index is not None:
+            mat = self.faiss_index.reconstruct_n(0, self.faiss_index.ntotal)
+            np.save(base + ".matrix.npy", mat)
+            manifest.update(ntotal=int(mat.shape[0]), dim=int(mat.shape[1]),
+                            matrix=os.path.basename(base + ".matrix.npy"))
+        with open(index_path, "w") as f:  # JSON under the reference's file name
+            json.dump(manifest, f)
+        self.logger.info(f"Stage 1 index saved to {index_path}")
+
+    def load_index(self, index_path: Optional[str] = None):
+        if index_path is None:
+            index_path = os.path.join(self.config.index_dir, "stage1_index.pkl")
+        if not os.path.exists(index_path):
+            self.logger.warning(f"Index file not found: {index_path}")
+            return
+        with open(index_path, "rb") as f:
+            head = f.read(1)
+        if head != b"{":
+            raise ValueError(f"{index_path} is not a tristage-rag_amd index manifest (a pickle written by the "
+                             "reference is not loaded: unpickling executes code)")
+        manifest = json.load(open(index_path))
+        self.documents = manifest["documents"]
+        self.doc_metadata = manifest["doc_metadata"]
+        self.faiss_index = None
+        if manifest.get("matrix"):
+            mat = np.load(os.path.join(os.path.dirname(os.path.abspath(index_path)), manifest["matrix"]),
+                          allow_pickle=False)
+            self._create_faiss_index(mat.astype(np.float32))
+        if self.config.enable_bm25 and self.documents:
+            self.bm25_index = BM25Index()
+            self.bm25_index.fit(self.documents)
+        self.logger.info(f"Stage 1 index loaded from {index_path}")
+
+    def get_stats(self) -> Dict[str, Any]:
+        return {"total_documents": len(self.documents), "embedding_dimension": self.embedding_dim,
+                "faiss_index_type": type(self.faiss_index).__name__ if self.faiss_index else None,
+                "bm25_enabled": self.config.enable_bm25,
+                "bm25_vocabulary_size": len(self.bm25_index.vocabulary) if self.bm25_index else 0,
+                "config": self.config.__dict__}

@@ -1,0 +1,214 @@
+"""Stage 2: ColBERT-style MaxSim rescoring, batched on the GPU.
+
+Mirror of reference src/stage2_rescorer.py (class ``ColBERTScorer``, config
+``Stage2Config``, same method names and result fields).  The arithmetic is the
+reference's — token embeddings = ``last_hidden_state`` of a plain ``AutoModel``
+truncated to each text's true length (:134-165, :207-242), score =
+mean/softmax-weighted max cosine (:167-201), stable descending sort, keep
+``top_k_candidates`` (:293-297) — but instead of one tiny matmul plus one
+``.item()`` host sync per candidate (:268-276) all candidates of a query are
+scored by ONE launch of the HIP MaxSim kernel (ts_maxsim) on their packed token
+matrices, and there is one device->host copy per query.
+
+Optional (``cache_document_embeddings``): token matrices are kept per document
+text, so a document is encoded once instead of once per query that retrieves it
+(SURVEY.md §8f-2); scores are unchanged up to batch-padding noise.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Stage2Config:
+    model_name: str = "lightonai/GTE-ModernColBERT-v1"
+    device: str = "auto"
+    cache_dir: str = "./models"
+    max_seq_length: int = 192
+    batch_size: int = 16
+    top_k_candidates: int = 100
+    use_fp16: bool = True
+    pooling_method: str = "cls"  # "cls", "mean", or "max"
+    normalize_embeddings: bool = True
+    scoring_method: str = "maxsim"  # "maxsim" or "colbert"
+    use_gpu_if_available: bool = True
+    # additive
+    cache_document_embeddings: bool = False
+
+
+class ColBERTScorer:
+    """ColBERT-style MaxSim scoring for multi-vector retrieval."""
+
+    def __init__(self, config: Stage2Config, model: Any = None, tokenizer: Any = None,
+                 maxsim_fn: Optional[Callable] = None):
+        self.config = config
+        self.logger = logging.getLogger(__name__)
+        self.model = model
+        self.tokenizer = tokenizer
+        self.device = self._get_device()
+        self._maxsim_fn = maxsim_fn
+        self._doc_cache: Dict[str, torch.Tensor] = {}
+        self._load_model()
+
+    def _get_device(self) -> str:
+        if self.config.device == "auto":
+            return "cuda" if (torch.cuda.is_available() and self.config.use_gpu_if_available) else "cpu"
+        return self.config.device
+
+    def _load_model(self) -> None:
+        if self.model is None or self.tokenizer is None:
+            from .encoders import load_backbone
+            self.logger.info(f"Loading Stage 2 model: {self.config.model_name}")
+            self.tokenizer, self.model, _ = load_backbone(self.config.model_name, self.config.cache_dir, "base")
+        self.model.to(self.device)
+        self.model.eval()
+        self.use_amp = self.config.use_fp16 and str(self.device).startswith("cuda")
+
+    # -- encoding ------------------------------------------------------------
+    def _model_inputs(self, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        keep = ("input_ids", "attention_mask", "token_type_ids")
+        out = {k: v.to(self.device) for k, v in enc.items() if k in keep}
+        if "token_type_ids" in out and not hasattr(self.model.config, "type_vocab_size"):
+            out.pop("token_type_ids")
+        return out
+
+    def _forward(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
+        with torch.no_grad():
+            if self.use_amp:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    return self.model(**enc).last_hidden_state
+            return self.model(**enc).last_hidden_state
+
+    def _tokenize_batch(self, texts: List[str]) -> Dict[str, torch.Tensor]:
+        """reference :100-113"""
+        texts = [t if t and t.strip() else "empty" for t in texts]
+        enc = self.tokenizer(texts, truncation=True, padding=True, max_length=self.config.max_seq_length,
+                             return_tensors="pt")
+        return self._model_inputs(enc)
+
+    def _pool_embeddings(self, embeddings: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """reference :115-132 (not used by the scoring path; kept for API parity)"""
+        if self.config.pooling_method == "cls":
+            return embeddings[:, 0, :]
+        if self.config.pooling_method == "mean":
+            m = attention_mask.unsqueeze(-1).expand(embeddings.size()).float()
+            return torch.sum(embeddings * m, 1) / torch.clamp(m.sum(1), min=1e-9)
+        if self.config.pooling_method == "max":
+            m = attention_mask.unsqueeze(-1).expand(embeddings.size()).float()
+            embeddings = embeddings.masked_fill(m == 0, -1e9)
+            return torch.max(embeddings, 1)[0]
+        raise ValueError(f"Unknown pooling method: {self.config.pooling_method}")
+
+    def _encode_single_text(self, text: str) -> torch.Tensor:
+        """reference :134-165 -> [1, L, H]"""
+        if not text or not text.strip():
+            text = "empty"
+        enc = self.tokenizer(text, truncation=True, max_length=self.config.max_seq_length,
+                             return_tensors="pt", padding=False)
+        enc = self._model_inputs(enc)
+        hidden = self._forward(enc)
+        n = int(enc["attention_mask"].sum().item())
+        return hidden[:, :n, :]
+
+    def encode_query(self, query: str) -> torch.Tensor:
+        return self._encode_single_text(query)
+
+    def encode_single_document(self, document: str) -> torch.Tensor:
+        return self._encode_single_text(document)
+
+    def encode_documents_batch(self, documents: List[str]) -> List[torch.Tensor]:
+        """reference :207-242 -> list of [L_i, H] (true lengths, padding cut off)."""
+        out: List[Optional[torch.Tensor]] = [None] * len(documents)
+        todo = list(range(len(documents)))
+        if self.config.cache_document_embeddings:
+            todo = []
+            for i, d in enumerate(documents):
+                hit = self._doc_cache.get(d)
+                if hit is not None:
+                    out[i] = hit
+                else:
+                    todo.append(i)
+        bs = self.config.batch_size
+        for s in range(0, len(todo), bs):
+            idx = todo[s:s + bs]
+            enc = self._tokenize_batch([documents[i] for i in idx])
+            hidden = self._forward(enc)
+            lens = enc["attention_mask"].sum(dim=1).tolist()  # one sync per batch, not per document
+            for j, i in enumerate(idx):
+                e = hidden[j, :int(lens[j]), :]
+                out[i] = e
+                if self.config.cache_document_embeddings:
+                    self._doc_cache[documents[i]] = e
+        return out  # type: ignore[return-value]
+
+    # -- scoring -------------------------------------------------------------
+    def _maxsim_score(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
+        """reference :167-183 for ONE pair — same HIP kernel as the batched path."""
+        return torch.tensor(self.score_all(query_embeddings, [doc_embeddings.reshape(-1, doc_embeddings.shape[-1])],
+                                           mode="maxsim")[0])
+
+    def _colbert_score(self, query_embeddings: torch.Tensor, doc_embeddings: torch.Tensor) -> torch.Tensor:
+        """reference :185-201 for ONE pair — same HIP kernel as the batched path."""
+        return torch.tensor(self.score_all(query_embeddings, [doc_embeddings.reshape(-1, doc_embeddings.shape[-1])],
+                                           mode="colbert")[0])
+
+    def score_all(self, query_embeddings: torch.Tensor, doc_embeddings_list: List[torch.Tensor],
+                  mode: Optional[str] = None) -> List[float]:
+        """Scores of every candidate with one kernel launch and one host copy."""
+        if not doc_embeddings_list:
+            return []
+        q = query_embeddings.squeeze(0).float().contiguous()
+        lens = [int(d.shape[0]) for d in doc_embeddings_list]
+        off = torch.zeros(len(lens) + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int32), 0)
+        packed = torch.cat([d.reshape(-1, q.shape[1]) for d in doc_embeddings_list], 0).float().contiguous()
+        fn = self._maxsim_fn
+        if fn is None:
+            from .index import maxsim  # HIP kernel; raises without the library or a GPU
+            fn = maxsim
+        scores = fn(q, packed, off.to(q.device), mode or self.config.scoring_method)
+        return [float(x) for x in scores.detach().cpu().tolist()]
+
+    def rescore_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        if not candidates:
+            return []
+        self.logger.info(f"Rescoring {len(candidates)} candidates with Stage 2")
+        query_embeddings = self.encode_query(query)
+        documents = [c["document"] for c in candidates]
+        doc_embeddings_list = self.encode_documents_batch(documents)
+        scores = self.score_all(query_embeddings, doc_embeddings_list)
+        scored = []
+        for cand, s in zip(candidates, scores):
+            u = cand.copy()
+            u["stage2_score"] = s
+            u["stage"] = "stage2"
+            scored.append(u)
+        scored.sort(key=lambda x: x["stage2_score"], reverse=True)  # stable, like the reference
+        top = scored[: self.config.top_k_candidates]
+        self.logger.info(f"Stage 2 rescoring completed. Top score: {top[0]['stage2_score'] if top else 0:.4f}")
+        return top
+
+    def compute_similarity_matrix(self, query: str, documents: List[str]) -> np.ndarray:
+        q = self.encode_query(query)
+        return np.array(self.score_all(q, self.encode_documents_batch(documents)))
+
+    def get_model_info(self) -> Dict[str, Any]:
+        return {"model_name": self.config.model_name, "device": self.device,
+                "max_seq_length": self.config.max_seq_length, "use_fp16": self.use_amp,
+                "pooling_method": self.config.pooling_method, "scoring_method": self.config.scoring_method,
+                "batch_size": self.config.batch_size,
+                "embedding_dim": self.model.config.hidden_size if self.model else None}
+
+    def clear_gpu_memory(self):
+        """The reference calls torch.cuda.empty_cache() after every query
+        (src/retrieval_pipeline.py:417-418); with 288 GB of HBM that only costs
+        allocator round trips, so this is a no-op.  See clear_document_cache()."""
+        return None
+
+    def clear_document_cache(self):
+        self._doc_cache.clear()

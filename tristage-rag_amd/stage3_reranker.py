@@ -1,0 +1,186 @@
+"""Stage 3: cross-encoder reranking.
+
+Mirror of reference src/stage3_reranker.py (``Stage3Config``,
+``CrossEncoderReranker``, ``AdaptiveCrossEncoderReranker``; same method names,
+result fields and arithmetic: pair preparation :113-118, activation :173-176,
+min-max normalisation :212-228, stable descending sort and top_k_final :256-260,
+adaptive batch size :328-344).  The forward pass is a batched bf16 run of the
+sequence-classification model on PyTorch-ROCm (tristage_rag_amd.encoders.
+CrossEncoderModel, the restatement of sentence_transformers.CrossEncoder the
+reference prefers at :65-70), with one device->host copy per rerank call.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class Stage3Config:
+    model_name: str = "cross-encoder/ms-marco-MiniLM-L6-v2"
+    device: str = "auto"
+    cache_dir: str = "./models"
+    max_length: int = 256
+    batch_size: int = 32
+    top_k_final: int = 20
+    use_fp16: bool = True
+    use_gpu_if_available: bool = True
+    activation_fxn: str = "sigmoid"  # "sigmoid" or "softmax" (HF path)
+    normalize_scores: bool = True
+
+
+class CrossEncoderReranker:
+    """Stage 3: cross-encoder reranker for the final ranking."""
+
+    def __init__(self, config: Stage3Config, model: Any = None):
+        self.config = config
+        self.logger = logging.getLogger(__name__)
+        self.model = model
+        self.tokenizer = None
+        self.device = self._get_device()
+        self._load_model()
+
+    def _get_device(self) -> str:
+        if self.config.device == "auto":
+            return "cuda" if (torch.cuda.is_available() and self.config.use_gpu_if_available) else "cpu"
+        return self.config.device
+
+    def _load_model(self) -> None:
+        if self.model is None:
+            from .encoders import CrossEncoderModel
+            self.logger.info(f"Loading Stage 3 model: {self.config.model_name}")
+            self.model = CrossEncoderModel(self.config.model_name, device=self.device,
+                                           max_length=self.config.max_length,
+                                           cache_folder=self.config.cache_dir,
+                                           use_amp=self.config.use_fp16)
+        # CrossEncoder-style object (predict on sentence pairs), like the reference's preferred path
+        self.use_sentence_transformers = hasattr(self.model, "predict")
+        if not self.use_sentence_transformers:
+            self.tokenizer = getattr(self.model, "tokenizer", None)
+        self.use_amp = self.config.use_fp16 and str(self.device).startswith("cuda")
+
+    def _prepare_input_pairs(self, query: str, documents: List[str]) -> List[Tuple[str, str]]:
+        return [(query, doc) for doc in documents]
+
+    def _predict_with_sentence_transformers(self, pairs: List[Tuple[str, str]]) -> List[float]:
+        """reference :120-137"""
+        sentence_pairs = [[q, d] for q, d in pairs]
+        scores = self.model.predict(sentence_pairs, batch_size=self.config.batch_size, show_progress_bar=False)
+        return np.asarray(scores).tolist()
+
+    def _predict_with_huggingface(self, pairs: List[Tuple[str, str]]) -> List[float]:
+        """reference :139-190 — raw HF sequence-classification model + tokenizer."""
+        all_scores: List[float] = []
+        for i in range(0, len(pairs), self.config.batch_size):
+            batch = pairs[i:i + self.config.batch_size]
+            enc = self.tokenizer([p[0] for p in batch], [p[1] for p in batch], truncation=True, padding=True,
+                                 max_length=self.config.max_length, return_tensors="pt")
+            enc = {k: v.to(self.device) for k, v in enc.items()}
+            with torch.no_grad():
+                if self.use_amp:
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        logits = self.model(**enc).logits
+                else:
+                    logits = self.model(**enc).logits
+                if self.config.activation_fxn == "sigmoid":
+                    scores = torch.sigmoid(logits.float()).squeeze(-1)
+                else:
+                    scores = F.softmax(logits.float(), dim=-1)[:, 1]
+                all_scores.extend(scores.cpu().tolist())
+        return all_scores
+
+    def predict(self, query: str, documents: List[str]) -> List[float]:
+        """reference :192-210"""
+        if not documents:
+            return []
+        pairs = self._prepare_input_pairs(query, documents)
+        scores = (self._predict_with_sentence_transformers(pairs) if self.use_sentence_transformers
+                  else self._predict_with_huggingface(pairs))
+        if self.config.normalize_scores:
+            scores = self._normalize_scores(scores)
+        return scores
+
+    def _normalize_scores(self, scores: List[float]) -> List[float]:
+        """reference :212-228"""
+        if not scores:
+            return scores
+        a = np.array(scores)
+        mn, mx = a.min(), a.max()
+        normalized = (a - mn) / (mx - mn) if mx > mn else np.zeros_like(a)
+        return normalized.tolist()
+
+    def rerank(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        """reference :230-264"""
+        if not candidates:
+            return []
+        self.logger.info(f"Reranking {len(candidates)} candidates with Stage 3")
+        scores = self.predict(query, [c["document"] for c in candidates])
+        reranked = []
+        for cand, s in zip(candidates, scores):
+            u = cand.copy()
+            u["stage3_score"] = s
+            u["stage"] = "stage3"
+            reranked.append(u)
+        reranked.sort(key=lambda x: x["stage3_score"], reverse=True)
+        final = reranked[: self.config.top_k_final]
+        self.logger.info(f"Stage 3 reranking completed. Top score: {final[0]['stage3_score'] if final else 0:.4f}")
+        return final
+
+    def batch_rerank(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]):
+        if not queries or not candidates_list:
+            return []
+        if len(queries) != len(candidates_list):
+            raise ValueError("Number of queries must match number of candidate lists")
+        return [self.rerank(q, c) for q, c in zip(queries, candidates_list)]
+
+    def get_model_info(self) -> Dict[str, Any]:
+        info = {"model_name": self.config.model_name, "device": self.device,
+                "max_length": self.config.max_length, "batch_size": self.config.batch_size,
+                "use_fp16": self.use_amp, "activation_function": self.config.activation_fxn,
+                "normalize_scores": self.config.normalize_scores, "top_k_final": self.config.top_k_final}
+        if self.use_sentence_transformers:
+            info["model_type"] = "CrossEncoder (tristage_rag_amd.encoders.CrossEncoderModel)"
+        else:
+            info["model_type"] = "HuggingFace AutoModel"
+            info["num_labels"] = getattr(self.model, "num_labels", None)
+        return info
+
+    def clear_gpu_memory(self):
+        return None  # see ColBERTScorer.clear_gpu_memory
+
+
+class AdaptiveCrossEncoderReranker(CrossEncoderReranker):
+    """Reranker that adapts its batch size to the input length (reference :321-367)."""
+
+    def __init__(self, config: Stage3Config, model: Any = None):
+        super().__init__(config, model=model)
+        self.max_text_length = config.max_length // 2
+
+    def _adaptive_batch_size(self, texts: List[str]) -> int:
+        if not texts:
+            return self.config.batch_size
+        avg = sum(len(t.split()) for t in texts) / len(texts)
+        if avg > 200:
+            return max(4, self.config.batch_size // 4)
+        elif avg > 100:
+            return max(8, self.config.batch_size // 2)
+        elif avg > 50:
+            return max(16, self.config.batch_size // 1)
+        return self.config.batch_size
+
+    def rerank(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        if not candidates:
+            return []
+        documents = [c["document"] for c in candidates]
+        adaptive = self._adaptive_batch_size([query] + documents)
+        original = self.config.batch_size
+        self.config.batch_size = adaptive  # not re-entrant, exactly like the reference (:358-365)
+        try:
+            return super().rerank(query, candidates)
+        finally:
+            self.config.batch_size = original
