@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true",
+                    help="wait for every batch before issuing the next (default: batches are enqueued "
+                         "back to back and completed + verified by finish() inside the timed region)")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     return ap.parse_args()
 
@@ -133,10 +136,22 @@ def main():
     torch.cuda.synchronize()
 
     def step(i):
-        return index.search(queries[i % len(queries)], args.k)
+        return index.search(queries[i % len(queries)], args.k, async_=not args.sync)
+
+    def finish():
+        if not args.sync:
+            index.finish()
 
     for i in range(args.warmup):
         step(i)
+    finish()
+    # per-batch latency with a host sync after every batch (reported, not the metric)
+    torch.cuda.synchronize()
+    tl = time.perf_counter()
+    for i in range(5):
+        index.search(queries[i % len(queries)], args.k)
+    torch.cuda.synchronize()
+    sync_latency_ms = (time.perf_counter() - tl) / 5 * 1e3
     local.set_profiling(True)
     local.timings(reset=True)
     torch.cuda.synchronize()
@@ -145,6 +160,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         D, I = step(i)
+    finish()                     # completes AND verifies every batch of the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -198,6 +214,9 @@ def main():
                                     f"queries, stage-1 exact top-{args.k}, row-sharded over {world} GPU(s)"
                                     + (", RCCL all-gather + HIP merge" if world > 1 else "")),
                        "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
+                       "submission": "synchronous per batch" if args.sync else
+                                     "batches enqueued back to back (async), verified by finish() in the timed region",
+                       "sync_batch_latency_ms": round(sync_latency_ms, 4),
                        "search_path": info["path"], "max_candidates_per_query": info["max_candidates"],
                        "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]}},
             "roofline": roof,

@@ -50,6 +50,8 @@ enum ts_metric { TS_METRIC_INNER_PRODUCT = 0 };
 /* ts_index_add / ts_index_search flags */
 #define TS_FLAG_HOST_PTR 1u     /* `rows` / `queries` / outputs are host memory */
 #define TS_FLAG_NO_FILTER 2u    /* search: force the dense (materialise+select) path */
+#define TS_FLAG_ASYNC 8u        /* search: enqueue only (device pointers); results are valid
+                                   and verified after ts_index_finish()            */
 #define TS_FLAG_NORMALIZE 4u    /* add: L2-normalise rows x/(|x|+1e-8) on device first
                                    (reference src/stage1_retriever.py:285-288) */
 
@@ -83,6 +85,18 @@ int ts_index_add(ts_index* h, const void* rows, int64_t n, int32_t rows_dtype,
 int ts_index_search(ts_index* h, const void* queries, int32_t nq,
                     int32_t q_dtype, int32_t k, float* out_scores,
                     int64_t* out_ids, uint32_t flags, void* stream);
+
+/* ---- asynchronous searches ------------------------------------------------
+ * With TS_FLAG_ASYNC ts_index_search only enqueues work on `stream` and returns;
+ * consecutive batches then run back to back on the GPU with no host round trip
+ * in between.  Each call gets a ticket (ts_index_last_ticket).  ts_index_finish
+ * synchronises the stream once and checks every unfinished search: the tickets
+ * whose fused filter could not prove exactness (rare) are
+ * returned in failed_tickets[0..*n_failed) and must be repeated by the caller
+ * with TS_FLAG_NO_FILTER (synchronously).  At most 64 calls may be unfinished.  */
+int64_t ts_index_last_ticket(const ts_index* h);
+int ts_index_finish(ts_index* h, void* stream, int64_t* failed_tickets, int32_t max_failed,
+                    int32_t* n_failed);
 
 /* ---- introspection -------------------------------------------------------
  * faiss_index.ntotal / .d                                                    */

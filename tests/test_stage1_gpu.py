@@ -206,3 +206,26 @@ def test_long_query_and_odd_hidden_size(torch_mod):
     out = maxsim(torch.from_numpy(q).cuda(), torch.from_numpy(np.concatenate(docs, 0)).cuda(),
                  torch.from_numpy(off).cuda()).cpu().numpy()
     np.testing.assert_allclose(out, oracle.maxsim_scores(q, docs), atol=2e-6, rtol=0)
+
+
+def test_async_searches_match_sync_and_repair_failures(torch_mod):
+    torch = torch_mod
+    corpus = make_corpus(120_000, 128, dtype="f16")
+    idx = _index(128, "f16", corpus)
+    qs = [torch.from_numpy(make_corpus(64, 128, seed=100 + i, dtype="f16")).cuda().half() for i in range(5)]
+    sync = [idx.search(q, 200) for q in qs]
+    outs = [idx.search(q, 200, async_=True) for q in qs]      # enqueued back to back
+    assert idx.finish() == []                                  # nothing needed a redo
+    for (D, I), (D0, I0) in zip(outs, sync):
+        assert torch.equal(I, I0) and torch.equal(D, D0)
+    assert idx.last_search_info()["path"] == "filter"
+    idx.close()
+    # an index where the filter cannot prove exactness (all scores tie): finish() repairs in place
+    row = make_corpus(1, 128, seed=1, dtype="f16")
+    idx = _index(128, "f16", np.repeat(row, 40_000, axis=0))
+    q = torch.from_numpy(make_corpus(4, 128, seed=2, dtype="f16")).cuda().half()
+    D, I = idx.search(q, 20, async_=True)
+    D2, I2 = idx.search(q, 20, async_=True)
+    assert len(idx.finish()) == 2
+    assert (I.cpu().numpy() == np.arange(20)[None, :]).all() and torch.equal(I, I2)
+    idx.close()

@@ -19,7 +19,7 @@ TS_OK = 0
 TS_ERR_INVALID, TS_ERR_HIP, TS_ERR_OOM, TS_ERR_EMPTY, TS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 TS_F32, TS_F16, TS_BF16 = 0, 1, 2
 TS_METRIC_INNER_PRODUCT = 0
-TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE = 1, 2, 4
+TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE, TS_FLAG_ASYNC = 1, 2, 4, 8
 
 # name -> (restype, argtypes); mirrors include/tristage.h one to one
 SIGNATURES = {
@@ -36,6 +36,8 @@ SIGNATURES = {
     "ts_index_set_id_offset": (c_int32, [c_void_p, c_int64]),
     "ts_index_reconstruct": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_uint32, c_void_p]),
     "ts_index_last_search_info": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "ts_index_last_ticket": (c_int64, [c_void_p]),
+    "ts_index_finish": (c_int32, [c_void_p, c_void_p, POINTER(c_int64), c_int32, POINTER(c_int32)]),
     "ts_index_set_profiling": (c_int32, [c_void_p, c_int32]),
     "ts_index_get_timings": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "ts_merge_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -72,6 +72,8 @@ void release(DevBuf& b) {
 
 }  // namespace
 #define TS_NPHASE 8
+#define TS_ASYNC_SLOTS 256
+#define TS_SLOT_WORDS 80   // 64 counts + status word, padded
 namespace {
 // tuning constants of the filter path (DESIGN.md "threshold sampling")
 constexpr int64_t kMinFilterRows = 32768;   // below this the dense path is used
@@ -99,6 +101,14 @@ struct ts_index {
   DevBuf stage, den, qstage, out_s, out_i;
   uint32_t* host_status = nullptr;  // pinned + mapped: written by the select kernel
   uint32_t* host_status_dev = nullptr;  // device view of host_status
+  // asynchronous searches (TS_FLAG_ASYNC): each pass reports into its own slot of
+  // the mapped host ring; ts_index_finish() syncs once and inspects them all
+  struct Pending { int64_t ticket; int slot; int nq; uint32_t S; uint32_t m; hipEvent_t e0, e1; };
+  Pending pending[TS_ASYNC_SLOTS];
+  int npending = 0;
+  uint64_t slot_next = 0;
+  int64_t next_ticket = 0;
+  hipEvent_t async_ev[2 * TS_ASYNC_SLOTS] = {};
   // optional per-phase timing with HIP events on the caller's stream
   bool profiling = false;
   hipEvent_t ev[TS_NPHASE + 1] = {};
@@ -193,7 +203,7 @@ extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metri
   int st = ensure(h->small, 4096);
   if (st == TS_OK) st = ensure(h->qimg, (size_t)L.kg * 2 * 1024);
   if (st == TS_OK &&
-      (hipHostMalloc((void**)&h->host_status, 512, hipHostMallocMapped) != hipSuccess ||
+      (hipHostMalloc((void**)&h->host_status, (size_t)(TS_ASYNC_SLOTS + 1) * TS_SLOT_WORDS * 4, hipHostMallocMapped) != hipSuccess ||
        hipHostGetDevicePointer((void**)&h->host_status_dev, h->host_status, 0) != hipSuccess)) {
     ts_set_error("hipHostMalloc(mapped) failed");
     st = TS_ERR_HIP;
@@ -217,6 +227,8 @@ extern "C" int ts_index_destroy(ts_index* h) {
   for (DevBuf* b : bufs) release(*b);
   if (h->host_status) (void)hipHostFree(h->host_status);
   for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->async_ev)
     if (e) (void)hipEventDestroy(e);
   delete h;
   return TS_OK;
@@ -399,6 +411,7 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
     prof_mark(h, 5, s);
     TS_CHECK(dense_path(h, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
+    if (flags & TS_FLAG_ASYNC) { h->nev = 0; return TS_OK; }  // exact by construction: nothing to verify
     TS_HIP(hipStreamSynchronize(s));
     prof_collect(h);
     return TS_OK;
@@ -466,16 +479,36 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   p.status = h->status();
   // the select kernel reports the candidate counts and the status word straight
   // into mapped host memory: no copy kernel between it and the sync
-  p.host_report = h->host_status_dev;
-  for (int i = 0; i < 65; ++i) h->host_status[i] = 0;
+  const bool async = (flags & TS_FLAG_ASYNC) != 0;
+  // synchronous searches use the extra last slot, asynchronous ones rotate through the ring
+  const int slot = async ? (int)(h->slot_next++ % TS_ASYNC_SLOTS) : TS_ASYNC_SLOTS;
+  uint32_t* rep = h->host_status + (size_t)slot * TS_SLOT_WORDS;
+  p.host_report = h->host_status_dev + (size_t)slot * TS_SLOT_WORDS;
+  for (int i = 0; i < 65; ++i) rep[i] = 0;
   TS_CHECK(ts_launch_select(p, nq, s));
   prof_mark(h, -1, s);
+  if (async) {
+    // verified later, by ts_index_finish(); nothing here waits for the GPU
+    ts_index::Pending& pe = h->pending[h->npending];
+    pe.ticket = h->next_ticket; pe.slot = slot; pe.nq = nq; pe.S = (uint32_t)S; pe.m = m;
+    pe.e0 = pe.e1 = nullptr;
+    if (h->profiling && h->nev >= 5) {  // keep the scan+filter interval of this pass
+      pe.e0 = h->ev[3]; pe.e1 = h->ev[4];
+      // hand the two events over and give the handle fresh ones
+      hipEvent_t n0 = nullptr, n1 = nullptr;
+      if (hipEventCreate(&n0) == hipSuccess && hipEventCreate(&n1) == hipSuccess) { h->ev[3] = n0; h->ev[4] = n1; }
+      else { pe.e0 = pe.e1 = nullptr; }
+    }
+    h->nev = 0;
+    ++h->npending;
+    return TS_OK;
+  }
   TS_HIP(hipStreamSynchronize(s));
   prof_collect(h);
   uint32_t maxc = 0;
-  for (int i = 0; i < nq; ++i) maxc = std::max(maxc, h->host_status[i]);
+  for (int i = 0; i < nq; ++i) maxc = std::max(maxc, rep[i]);
   h->info[0] = 1; h->info[1] = maxc; h->info[2] = S; h->info[3] = m;
-  if (h->host_status[64] != 0) {
+  if (rep[64] != 0) {
     // a threshold was too high (fewer than k survivors) or too low (candidate
     // list overflowed, e.g. massive score ties): redo this pass exactly.
     h->info[0] = 2;
@@ -504,6 +537,15 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   const int qp = (ts_scan_lds_bytes(h->L, 2) <= 160 * 1024) ? 64 : 32;  // queries per pass
+  if (flags & TS_FLAG_ASYNC) {
+    if (flags & TS_FLAG_HOST_PTR) { ts_set_error("TS_FLAG_ASYNC needs device pointers"); return TS_ERR_INVALID; }
+    const int passes = (nq + qp - 1) / qp;
+    if (passes > 4) { ts_set_error("TS_FLAG_ASYNC: at most %d queries per call", 4 * qp); return TS_ERR_INVALID; }
+    if (h->npending + passes > TS_ASYNC_SLOTS / 4) {
+      ts_set_error("too many unfinished asynchronous searches; call ts_index_finish()");
+      return TS_ERR_INVALID;
+    }
+  }
   const size_t qrow = (size_t)h->L.dim * dtype_size(q_dtype);
   const void* dq = queries;
   float* ds = out_scores;
@@ -523,11 +565,49 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
     TS_CHECK(search_pass(h, (const char*)dq + (size_t)q0 * qrow, c, q_dtype, k,
                          ds + (size_t)q0 * k, di + (size_t)q0 * k, flags, s));
   }
+  if (flags & TS_FLAG_ASYNC) ++h->next_ticket;
   if (host) {
     TS_HIP(hipMemcpyAsync(out_scores, ds, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
     TS_HIP(hipMemcpyAsync(out_ids, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     TS_HIP(hipStreamSynchronize(s));
   }
+  return TS_OK;
+}
+
+extern "C" int64_t ts_index_last_ticket(const ts_index* h) { return h ? h->next_ticket - 1 : -1; }
+
+extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_tickets, int32_t max_failed,
+                               int32_t* n_failed) {
+  if (!h || !n_failed || max_failed < 0 || (max_failed > 0 && !failed_tickets)) {
+    ts_set_error("bad arguments to finish");
+    return TS_ERR_INVALID;
+  }
+  DeviceGuard g(h->device);
+  TS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int nf = 0;
+  uint32_t maxc = 0;
+  for (int i = 0; i < h->npending; ++i) {
+    ts_index::Pending& pe = h->pending[i];
+    const uint32_t* rep = h->host_status + (size_t)pe.slot * TS_SLOT_WORDS;
+    for (int q = 0; q < pe.nq; ++q) maxc = std::max(maxc, rep[q]);
+    if (rep[64] != 0) {
+      if (nf == 0 || failed_tickets[nf - 1] != pe.ticket) {
+        if (nf < max_failed) failed_tickets[nf] = pe.ticket;
+        ++nf;
+      }
+    }
+    if (pe.e0 && pe.e1) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pe.e0, pe.e1) == hipSuccess) { h->phase_ms[3] += ms; h->phase_cnt[3] += 1; }
+      (void)hipEventDestroy(pe.e0);
+      (void)hipEventDestroy(pe.e1);
+    }
+    h->info[0] = 1; h->info[2] = pe.S; h->info[3] = pe.m;
+  }
+  if (h->npending) h->info[1] = maxc;
+  h->npending = 0;
+  *n_failed = nf;
+  if (nf > max_failed) { ts_set_error("%d searches need a redo but only %d tickets fit", nf, max_failed); return TS_ERR_INVALID; }
   return TS_OK;
 }
 

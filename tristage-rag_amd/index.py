@@ -68,6 +68,7 @@ class FlatIPIndex:
                                              _lib.TS_METRIC_INNER_PRODUCT, self.device,
                                              ctypes.byref(self._h)))
         self.is_trained = True  # FAISS attribute; a flat index needs no training
+        self._pending = {}      # ticket -> (q, k, D, I) of unfinished async searches
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -123,13 +124,24 @@ class FlatIPIndex:
                                           None))
         return None
 
-    def search(self, q, k: int, exact_dense: bool = False):
+    def search(self, q, k: int, exact_dense: bool = False, async_: bool = False):
         """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
-        numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out."""
+        numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out.
+
+        ``async_=True`` (CUDA tensors only): the work is only enqueued on the current
+        stream and the output tensors are returned at once; they are complete and
+        verified after :meth:`finish`.  Batches issued this way run back to back on
+        the GPU without a host round trip between them."""
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
         flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
+        if async_:
+            if not (_is_tensor(q) and q.is_cuda):
+                raise ValueError("async_ search needs a CUDA tensor")
+            if len(self._pending) >= 60:
+                self.finish()
+            flags |= _lib.TS_FLAG_ASYNC
         if _is_tensor(q) and q.is_cuda:
             torch = _torch()
             if q.dim() != 2 or q.shape[1] != self.d:
@@ -140,6 +152,8 @@ class FlatIPIndex:
             I = torch.empty((B, k), dtype=torch.int64, device=q.device)
             self._search_raw(q.data_ptr(), B, _tensor_dtype(q), k, D.data_ptr(), I.data_ptr(),
                              flags, _stream_ptr(self.device))
+            if async_:
+                self._pending[int(self._lib.ts_index_last_ticket(self._h))] = (q, k, D, I)
             return D, I
         if _is_tensor(q):
             q = q.detach().float().numpy()
@@ -164,6 +178,23 @@ class FlatIPIndex:
             # same exception type and text as reference src/stage1_retriever.py:370-371
             raise ValueError("No documents indexed. Call add_documents() first.")
         _lib.check(code)
+
+    def finish(self):
+        """Complete every asynchronous search: one stream sync, then the (rare)
+        batches whose fused filter could not prove exactness are repeated on the
+        exact dense path, in place.  Returns the tickets that were repeated."""
+        failed = (ctypes.c_int64 * 64)()
+        nf = ctypes.c_int32(0)
+        _lib.check(self._lib.ts_index_finish(self._h, ctypes.c_void_p(_stream_ptr(self.device)) if
+                                             _stream_ptr(self.device) else None, failed, 64, ctypes.byref(nf)))
+        redone = []
+        for i in range(nf.value):
+            q, k, D, I = self._pending[int(failed[i])]
+            self._search_raw(q.data_ptr(), q.shape[0], _tensor_dtype(q), k, D.data_ptr(), I.data_ptr(),
+                             _lib.TS_FLAG_NO_FILTER, _stream_ptr(self.device))
+            redone.append(int(failed[i]))
+        self._pending.clear()
+        return redone
 
     def reconstruct_n(self, i0: int = 0, n: Optional[int] = None) -> np.ndarray:
         """Rows [i0, i0+n) as float32 (after storage rounding)."""

@@ -61,6 +61,7 @@ class ShardedFlatIPIndex:
             from .index import merge_topk
             merge_fn = merge_topk
         self.merge_fn = merge_fn
+        self._pending = []
 
     # -- FAISS duck type ----------------------------------------------------
     @property
@@ -79,12 +80,17 @@ class ShardedFlatIPIndex:
             raise ValueError(f"expected {self.n_total} rows, got {rows.shape[0]}")
         self.local_index.add(rows[self.lo:self.hi])
 
-    def search(self, q, k: int):
+    def search(self, q, k: int, async_: bool = False):
         """Global top-k for the replicated query batch `q` (tensor).  Returns
-        tensors (D float32 [B,k], I int64 [B,k]) identical on every rank."""
+        tensors (D float32 [B,k], I int64 [B,k]) identical on every rank.
+
+        ``async_=True``: local search, all-gather and merge are only enqueued (all
+        three are stream-ordered); call :meth:`finish` before reading the result."""
         import torch
+        if async_ and len(self._pending) >= 48:
+            self.finish()
         if self.hi > self.lo:
-            D, I = self.local_index.search(q, k)
+            D, I = (self.local_index.search(q, k, async_=True) if async_ else self.local_index.search(q, k))
             if not torch.is_tensor(D):
                 D, I = torch.from_numpy(D), torch.from_numpy(I)
         else:  # an empty shard contributes only padding
@@ -94,7 +100,40 @@ class ShardedFlatIPIndex:
         if self.world_size == 1:
             return D, I
         Dg, Ig = self._all_gather(D, I)
-        return self.merge_fn(Dg, Ig)
+        out = self.merge_fn(Dg, Ig)
+        if async_:
+            self._pending.append((q, k, D, I, out))
+        return out
+
+    def finish(self):
+        """Complete asynchronous searches on every rank.  If ANY rank had to repeat a
+        local search, all ranks repeat the exchange for that batch (collectively)."""
+        import torch
+        redone_local = set(self.local_index.finish()) if hasattr(self.local_index, "finish") else set()
+        if self.world_size == 1 or not self._pending:
+            self._pending.clear()
+            return
+        # the i-th pending entry of every rank is the same batch; local tickets are
+        # consecutive, so "repeated" maps to positions from the end
+        last = self._last_ticket()
+        flags = torch.zeros(len(self._pending), dtype=torch.int32, device=self._pending[0][4][0].device)
+        for t in redone_local:
+            pos = len(self._pending) - 1 - (last - t)
+            if 0 <= pos < len(self._pending):
+                flags[pos] = 1
+        self._dist.all_reduce(flags, op=self._dist.ReduceOp.MAX, group=self.group)
+        for pos in torch.nonzero(flags).flatten().tolist():
+            q, k, D, I, out = self._pending[pos]
+            Dg, Ig = self._all_gather(D, I)          # D, I were corrected in place by local finish()
+            Dn, In = self.merge_fn(Dg, Ig)
+            out[0].copy_(Dn)
+            out[1].copy_(In)
+        torch.cuda.current_stream().synchronize() if flags.is_cuda else None
+        self._pending.clear()
+
+    def _last_ticket(self) -> int:
+        li = self.local_index
+        return int(li._lib.ts_index_last_ticket(li._h)) if hasattr(li, "_lib") else -1
 
     def _all_gather(self, D, I):
         """One collective: [scores | ids] packed as bytes -> [R, B, k] pair."""
