@@ -1,0 +1,70 @@
+"""GPU: the shard exchange + merge on real kernels.  The box has one GPU, so
+(a) R shards live on the same device and their real search outputs are merged by
+the HIP merge kernel, and (b) ShardedFlatIPIndex runs its RCCL all-gather + merge
+code path in a world of one rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import check_topk, make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R", [2, 8])
+def test_shards_merged_on_device_equal_unsharded(R):
+    import torch
+    from tristage_rag_amd.index import FlatIPIndex, merge_topk
+    from tristage_rag_amd.sharded import shard_bounds
+    n, d, k, B = 200_000, 128, 1000, 64
+    rng = np.random.default_rng(8)
+    corpus = make_corpus(n // 2, d, dtype="f16")
+    corpus = np.concatenate([corpus, corpus[rng.permutation(n // 2)]])      # every row twice: ties across shards
+    queries = make_corpus(B, d, seed=4321, dtype="f16")
+    q = torch.from_numpy(queries).cuda().half()
+    whole = FlatIPIndex(d, dtype="f16")
+    whole.add(corpus)
+    D0, I0 = whole.search(q, k)
+    parts = []
+    for r in range(R):
+        lo, hi = shard_bounds(n, R, r)
+        idx = FlatIPIndex(d, dtype="f16")
+        idx.add(corpus[lo:hi])
+        idx.set_id_offset(lo)
+        parts.append(idx.search(q, k))
+        idx.close()
+    D, I = merge_topk(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(I, I0) and torch.equal(D, D0)
+    check_topk(D.cpu().numpy()[:4], I.cpu().numpy()[:4], corpus, queries[:4], k)
+    whole.close()
+
+
+def test_sharded_index_rccl_world_of_one():
+    import torch
+    import torch.distributed as dist
+    from tristage_rag_amd.sharded import ShardedFlatIPIndex
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n, d, k = 100_000, 128, 100
+        corpus = make_corpus(n, d, dtype="f16")
+        queries = make_corpus(64, d, seed=9, dtype="f16")
+        idx = ShardedFlatIPIndex(d, n, dtype="f16", device=0)
+        idx.always_exchange = True
+        idx.add_global(torch.from_numpy(corpus).cuda().half())
+        q = torch.from_numpy(queries).cuda().half()
+        D, I = idx.search(q, k)
+        check_topk(D.cpu().numpy(), I.cpu().numpy(), corpus, queries, k)
+        outs = [idx.search(q, k, async_=True) for _ in range(3)]
+        idx.finish()
+        for Da, Ia in outs:
+            assert torch.equal(Ia, I) and torch.equal(Da, D)
+    finally:
+        dist.destroy_process_group()

@@ -62,6 +62,7 @@ class ShardedFlatIPIndex:
             merge_fn = merge_topk
         self.merge_fn = merge_fn
         self._pending = []
+        self.always_exchange = False  # tests: run the collective + merge even for one rank
 
     # -- FAISS duck type ----------------------------------------------------
     @property
@@ -97,7 +98,7 @@ class ShardedFlatIPIndex:
             B = q.shape[0]
             D = torch.full((B, k), -3.4028234663852886e38, dtype=torch.float32, device=q.device)
             I = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_exchange:
             return D, I
         Dg, Ig = self._all_gather(D, I)
         out = self.merge_fn(Dg, Ig)
@@ -110,7 +111,7 @@ class ShardedFlatIPIndex:
         local search, all ranks repeat the exchange for that batch (collectively)."""
         import torch
         redone_local = set(self.local_index.finish()) if hasattr(self.local_index, "finish") else set()
-        if self.world_size == 1 or not self._pending:
+        if (self.world_size == 1 and not self.always_exchange) or not self._pending:
             self._pending.clear()
             return
         # the i-th pending entry of every rank is the same batch; local tickets are
