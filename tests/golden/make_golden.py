@@ -155,6 +155,14 @@ def main() -> None:
         hc.append({"task_name": task, "kwargs": kw, "is_corpus": bool(tm._is_corpus_encoding(task, kw))})
     kat["is_corpus_encoding"] = hc
 
+    # ---- chunking of the config-0 caller (non_mcp/embed_and_query.py:31-53)
+    from non_mcp.embed_and_query import chunk_text
+    base = ("Sentence number %d ends here. " * 1)
+    long_text = "".join(base % i for i in range(120)) + "\n" + "tail without period " * 30
+    texts = ["", "   ", "short text.", long_text, "x" * 2500, ("para one.\n" * 150)]
+    kat["chunk_text"] = [{"text": t, "chunk_size": cs, "overlap": ov, "chunks": chunk_text(t, cs, ov)}
+                         for t in texts for cs, ov in ((1000, 200), (300, 50))]
+
     os.chdir(cwd)
     with open(OUT, "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)

@@ -337,3 +337,25 @@ def test_hash_tokenizer_and_encoders():
     ce = CrossEncoderModel("random:tiny", device="cpu")
     s = ce.predict([["q", "d1"], ["q", "a longer document"]], batch_size=1)
     assert s.shape == (2,) and ((s > 0) & (s < 1)).all()
+
+
+# ------------------------------------------------------------------ config-0 caller
+def test_chunk_text_and_three_stage_system(encoder, tmp_path):
+    from tristage_rag_amd.three_stage_system import AppConfig, ThreeStageRetrievalSystem, chunk_text
+    for case in KAT["chunk_text"]:
+        assert chunk_text(case["text"], case["chunk_size"], case["overlap"]) == case["chunks"]
+    s1 = _stage1(encoder, tmp_path)
+    s2 = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=50),
+                       maxsim_fn=oracle_maxsim)
+    s3 = CrossEncoderReranker(Stage3Config(model_name="random:tiny", device="cpu", top_k_final=20))
+    sys_ = ThreeStageRetrievalSystem(AppConfig(device="cpu"), stage1=s1, stage2=s2, stage3=s3)
+    assert sys_.search("anything")["error"].startswith("No documents indexed")
+    assert sys_.add_documents(DOCS + [DOCS[0], "  "]) == 5 and sys_.add_documents(DOCS) == 0
+    out = sys_.search("neural networks attention", top_k=3)
+    assert set(out) == {"query", "results", "stage1_time", "stage2_time", "stage3_time", "total_time",
+                        "candidate_count", "final_count"}
+    assert out["candidate_count"] == 5 and out["final_count"] == 3
+    r = out["results"][0]
+    assert set(r) == {"rank", "doc_id", "document", "final_score", "stage1_score", "stage2_score", "stage3_score"}
+    assert r["rank"] == 1 and r["final_score"] == r["stage3_score"] == 1.0
+    assert len(sys_.search_history) == 1
