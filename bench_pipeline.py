@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: the full three-stage pipeline (BASELINE.json configs[2] shape:
+~3.6 k documents, stage 1 top-1000 -> stage 2 keep 100 -> stage 3 top-10, bf16) on
+one MI355X with RANDOMLY INITIALISED models of the reference's architectures (no
+weights exist offline), i.e. throughput and stage shares only — not a quality run.
+bench.py (stage-1 at 10M x 768) stays the headline measurement.
+
+    python bench_pipeline.py [--docs 3633] [--queries 16] [--cache]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=3633)
+    ap.add_argument("--queries", type=int, default=16)
+    ap.add_argument("--stage1", default="random:bert")          # 768-d bi-encoder stand-in
+    ap.add_argument("--stage2", default="random:modernbert")    # GTE-ModernColBERT backbone shape
+    ap.add_argument("--stage3", default="random:minilm")        # ms-marco-MiniLM-L6 shape
+    ap.add_argument("--cache", action="store_true", help="cache stage-2 token matrices per document")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+
+    rng = np.random.default_rng(0)
+    vocab = [f"w{i}" for i in range(5000)]
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(40, 160)))) for _ in range(args.docs)]
+    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(4, 16)))) for _ in range(args.queries)]
+    pc = PipelineConfig(stage1_model=args.stage1, stage2_model=args.stage2, stage3_model=args.stage3,
+                        device="cuda", cache_dir="/tmp/ts_models", index_dir="/tmp/ts_index",
+                        log_file="/tmp/ts_pipeline.log", log_level="WARNING",
+                        stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=False,
+                        stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
+                        stage3_batch_size=64, stage2_cache_document_embeddings=args.cache)
+    p = RetrievalPipeline(config=pc)
+    t0 = time.perf_counter()
+    p.add_documents(docs)
+    torch.cuda.synchronize()
+    t_index = time.perf_counter() - t0
+    p.search(queries[0])                      # warm-up
+    if args.cache:
+        for q in queries:                     # fill the cache (a real deployment fills it at add time)
+            p.search(q)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [p.search(q) for q in queries]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = {k: float(np.mean([o["timing"][k] for o in outs])) for k in ("stage1_time", "stage2_time", "stage3_time", "total_time")}
+    print(json.dumps({
+        "metric": "full 3-stage pipeline queries/sec (random-init models, throughput only)",
+        "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
+        "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
+                   "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
+                   "stage2_token_cache": args.cache},
+        "index_build_s": round(t_index, 3),
+        "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
+        "data": "synthetic"}))
+
+
+if __name__ == "__main__":
+    main()

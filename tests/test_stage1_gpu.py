@@ -229,3 +229,40 @@ def test_async_searches_match_sync_and_repair_failures(torch_mod):
     assert len(idx.finish()) == 2
     assert (I.cpu().numpy() == np.arange(20)[None, :]).all() and torch.equal(I, I2)
     idx.close()
+
+
+def test_ndcg_at_10_parity_on_scifact_shaped_synthetic_task():
+    """BASELINE.json: nDCG@10 within +-0.002 of the reference's exact CPU search.  No MTEB data
+    or weights exist offline, so the task is synthetic with the SciFact shape (5183 docs, 300
+    queries, d=384, fp32 embeddings as the reference's FAISS index holds them)."""
+    from tristage_rag_amd.evaluation import ndcg_at_k
+    rng = np.random.default_rng(11)
+    n, nq, d = 5183, 300, 384
+    docs = make_corpus(n, d, seed=5, dtype="f32")
+    rel = rng.integers(0, n, size=nq)
+    queries = docs[rel] + 0.9 * make_corpus(nq, d, seed=6, dtype="f32")     # noisy copies of the relevant doc
+    queries = (queries / np.linalg.norm(queries, axis=1, keepdims=True)).astype(np.float32)
+    qrels = {f"q{i}": {f"d{int(rel[i])}": 1, f"d{int((rel[i] * 7 + 1) % n)}": 1} for i in range(nq)}
+    idx = _index(d, "f32", docs)
+    D, I = idx.search(queries, 100)                       # cfg1: stage-1 only, top-100
+    D0, I0 = oracle.ip_topk(docs, queries, 100)
+    run = lambda DD, II: {f"q{i}": {f"d{int(j)}": float(s) for j, s in zip(II[i], DD[i])} for i in range(nq)}
+    got, want = ndcg_at_k(qrels, run(D, I), 10), oracle.ndcg_at_k(qrels, run(D0, I0), 10)
+    assert 0.3 < want < 1.0
+    assert abs(got - want) <= 0.002
+    assert np.array_equal(I, I0)                          # in fact the rankings are identical
+    idx.close()
+
+
+@pytest.mark.parametrize("n,d,k,B,dtype", [(32768 + 5, 32, 1, 33, "f16"), (40_001, 100, 7, 64, "bf16"),
+                                            (50_000, 1024, 64, 5, "bf16")])
+def test_filter_path_edge_shapes(n, d, k, B, dtype):
+    corpus = make_corpus(n, d, seed=21, dtype=dtype)
+    corpus[123] = 0.0                                      # an all-zero row scores exactly 0
+    queries = make_corpus(B, d, seed=22, dtype=dtype)
+    queries[0] = -queries[0]
+    idx = _index(d, dtype, corpus)
+    D, I = idx.search(queries, k)
+    assert idx.last_search_info()["path"] == "filter"
+    check_topk(D, I, corpus, queries, k)
+    idx.close()

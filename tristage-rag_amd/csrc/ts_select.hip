@@ -140,6 +140,44 @@ __device__ __forceinline__ void bitonic_desc(const SelParams& p, int64_t qbase, 
   }
 }
 
+// Same network for P <= 1024 with one key per thread held in a register: partners
+// closer than a wave (stride < 64) are exchanged with shuffles, so only the ten
+// stages with stride >= 64 go through LDS and a barrier (instead of all 55).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <int MODE>
+__device__ __forceinline__ void bitonic_desc_reg(const SelParams& p, int64_t qbase, uint64_t* keys,
+                                                 uint32_t P, int tid) {
+  // P <= SEL_THREADS; keys[0..P) in LDS on entry and on exit (sorted, best first)
+  uint64_t mine = ((uint32_t)tid < P) ? keys[tid] : 0ull;
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      uint64_t other;
+      if (stride < 64) {
+        other = shfl_xor_u64(mine, (int)stride);
+      } else {
+        __syncthreads();
+        if ((uint32_t)tid < P) keys[tid] = mine;
+        __syncthreads();
+        other = ((uint32_t)tid < P) ? keys[tid ^ stride] : 0ull;
+      }
+      const bool lower = (tid & stride) == 0;          // this thread keeps the element of the lower index
+      const bool desc = (tid & size) == 0;
+      // in a descending pair the lower index keeps the better key
+      const bool want_better = (lower == desc);
+      const bool other_better = key_before<MODE>(p, qbase, other, mine);
+      if ((uint32_t)tid < P && (want_better == other_better)) mine = other;
+    }
+  }
+  __syncthreads();
+  if ((uint32_t)tid < P) keys[tid] = mine;
+  __syncthreads();
+}
+
 template <int MODE>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32_t lds_keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -305,7 +343,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
   while (P < count) P <<= 1;
   for (uint32_t i = count + tid; i < P; i += SEL_THREADS) fin[i] = 0ull;
   __syncthreads();
-  bitonic_desc<MODE>(p, qbase, fin, P, tid);
+  if (P <= SEL_THREADS) bitonic_desc_reg<MODE>(p, qbase, fin, P, tid);
+  else bitonic_desc<MODE>(p, qbase, fin, P, tid);
 
   // ---- output
   float* os = p.out_scores + (int64_t)q * p.out_stride;
@@ -348,8 +387,12 @@ static int launch_select_t(const SelParams& p, int nq, hipStream_t stream) {
   const size_t lds = ((size_t)lds_keys + SEL_OUT_CAP + (MODE == SEL_MERGE64 ? SEL_TIE_CAP : 0)) * 8 +
                      (256 + 8 + 4) * 4;
   auto kern = select_kernel<MODE>;
-  TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  static bool attr_set = false;  // per instantiation (one process drives one GPU)
+  if (!attr_set) {
+    TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kern, dim3(nq), dim3(SEL_THREADS), lds, stream, p, lds_keys);
   TS_HIP(hipGetLastError());
   return TS_OK;
@@ -431,19 +474,41 @@ __global__ __launch_bounds__(SEL_THREADS) void tau_kernel(const float* sample, i
   constexpr uint32_t P = KEEP * SEL_THREADS;
   uint32_t idx = m ? m - 1 : 0;
   if (idx >= P) idx = P - 1;
-  // bitonic sort, descending (1024 keys: 55 stages of half a compare-exchange per thread)
-  for (uint32_t size = 2; size <= P; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
-        const uint32_t i = 2 * t - (t & (stride - 1));
-        const uint32_t j = i + stride;
-        const bool desc = (i & size) == 0;
-        const uint32_t a = keys[i], b = keys[j];
-        if (desc ? (b > a) : (a > b)) { keys[i] = b; keys[j] = a; }
+  if constexpr (KEEP == 1) {
+    // one key per thread: shuffles for stride < 64, LDS only for the ten wider stages
+    uint32_t mine = a0;
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        uint32_t other;
+        if (stride < 64) {
+          other = (uint32_t)__shfl_xor((int)mine, (int)stride, 64);
+        } else {
+          __syncthreads();
+          keys[tid] = mine;
+          __syncthreads();
+          other = keys[tid ^ stride];
+        }
+        const bool want_larger = (((tid & stride) == 0) == ((tid & size) == 0));
+        if (want_larger == (other > mine)) mine = other;
       }
-      __syncthreads();
     }
-  }
+    __syncthreads();
+    keys[tid] = mine;
+    __syncthreads();
+  } else {
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+          const uint32_t i = 2 * t - (t & (stride - 1));
+          const uint32_t j = i + stride;
+          const bool desc = (i & size) == 0;
+          const uint32_t a = keys[i], b = keys[j];
+          if (desc ? (b > a) : (a > b)) { keys[i] = b; keys[j] = a; }
+        }
+        __syncthreads();
+      }
+    }
+}
   if (tid == 0) {
     const uint32_t k = keys[idx];
     tau[q] = dbg_inf ? 3.402823466e38f : ((k == 0u) ? NEG_MAX : key2f(k));
