@@ -131,6 +131,15 @@ int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
                   int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
                   int32_t device, void* stream);
 
+/* Same, for lists that are not densely packed: list r's scores start at
+ * scores + r*score_list_stride (floats) and its ids at ids + r*id_list_stride
+ * (int64s) — e.g. each rank's [scores | ids] bytes gathered into one buffer, so
+ * the merge reads the all-gather output in place.                            */
+int ts_merge_topk_strided(const float* scores, const int64_t* ids, int32_t nlists,
+                          int32_t nq, int32_t k, int64_t score_list_stride,
+                          int64_t id_list_stride, float* out_scores, int64_t* out_ids,
+                          int32_t device, void* stream);
+
 /* ---- stage-2 MaxSim ------------------------------------------------------
  * replaces ColBERTScorer._maxsim_score / _colbert_score applied per candidate
  * (reference src/stage2_rescorer.py:167-201, loop at :268-276).

@@ -42,6 +42,8 @@ SIGNATURES = {
     "ts_index_get_timings": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
     "ts_merge_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_int32, c_void_p]),
+    "ts_merge_topk_strided": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                        c_void_p, c_void_p, c_int32, c_void_p]),
     "ts_maxsim": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                             c_int32, c_void_p, c_int32, c_void_p]),
     "ts_last_error": (c_char_p, []),

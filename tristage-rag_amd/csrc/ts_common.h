@@ -135,7 +135,8 @@ struct SelParams {
   const int64_t* ids64;    // MERGE64: [nq][stride] (entries with id<0 ignored)
   int64_t stride;          // elements between consecutive queries
   uint32_t seg_len;        // 0, or length of each concatenated list
-  int64_t seg_stride;      // distance between consecutive lists of a query
+  int64_t seg_stride;      // distance between consecutive lists of a query (scores)
+  int64_t seg_stride_ids;  // same for the int64 ids (MERGE64; 0 = same as seg_stride)
   uint32_t n;              // entries per query (if n_per_q == null)
   const uint32_t* n_per_q; // optional device counts, clamped to n_cap
   uint32_t n_cap;

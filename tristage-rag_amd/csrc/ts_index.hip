@@ -632,9 +632,9 @@ extern "C" int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8]
 }
 
 // ------------------------------------------------------------------ merge
-extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
-                             int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
-                             int32_t device, void* stream) {
+static int merge_impl(const float* scores, const int64_t* ids, int32_t nlists, int32_t nq, int32_t k,
+                      int64_t score_list_stride, int64_t id_list_stride, float* out_scores,
+                      int64_t* out_ids, int32_t device, void* stream) {
   if (!scores || !ids || !out_scores || !out_ids || nlists <= 0 || nq < 0 || k <= 0) {
     ts_set_error("bad arguments to merge");
     return TS_ERR_INVALID;
@@ -652,7 +652,8 @@ extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nl
   p.ids64 = ids;
   p.stride = k;                       // query q of list 0 starts at q*k
   p.seg_len = (uint32_t)k;
-  p.seg_stride = (int64_t)nq * k;     // next list
+  p.seg_stride = score_list_stride;   // next list (scores)
+  p.seg_stride_ids = id_list_stride;  // next list (ids)
   p.n = (uint32_t)(nlists * k);
   p.k = k;
   p.out_scores = out_scores;
@@ -660,6 +661,21 @@ extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nl
   p.out_stride = k;
   TS_CHECK(ts_launch_select(p, nq, (hipStream_t)stream));
   return TS_OK;
+}
+
+extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
+                             int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
+                             int32_t device, void* stream) {
+  return merge_impl(scores, ids, nlists, nq, k, (int64_t)nq * k, (int64_t)nq * k, out_scores, out_ids,
+                    device, stream);
+}
+
+extern "C" int ts_merge_topk_strided(const float* scores, const int64_t* ids, int32_t nlists,
+                                     int32_t nq, int32_t k, int64_t score_list_stride,
+                                     int64_t id_list_stride, float* out_scores, int64_t* out_ids,
+                                     int32_t device, void* stream) {
+  return merge_impl(scores, ids, nlists, nq, k, score_list_stride, id_list_stride, out_scores, out_ids,
+                    device, stream);
 }
 
 // ------------------------------------------------------------------ maxsim

@@ -40,6 +40,13 @@ __device__ __forceinline__ int64_t entry_addr(const SelParams& p, int64_t qbase,
   if (p.seg_len == 0) return qbase + e;
   return qbase + (int64_t)(e / p.seg_len) * p.seg_stride + (e % p.seg_len);
 }
+// the int64 ids of a merge may sit at another list pitch than the scores (packed
+// [scores | ids] per rank, as the all-gather delivers them)
+__device__ __forceinline__ int64_t id_addr(const SelParams& p, int64_t qbase, uint32_t e) {
+  if (p.seg_len == 0) return qbase + e;
+  const int64_t pitch = p.seg_stride_ids ? p.seg_stride_ids : p.seg_stride;
+  return qbase + (int64_t)(e / p.seg_len) * pitch + (e % p.seg_len);
+}
 
 template <int MODE>
 __device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase, uint32_t i) {
@@ -53,7 +60,7 @@ __device__ __forceinline__ uint64_t load_key(const SelParams& p, int64_t qbase, 
     if (id < 0) return 0ull;  // padding entry of a short list
     tb = (uint32_t)id;
   } else {
-    if (p.ids64[a] < 0) return 0ull;
+    if (p.ids64[id_addr(p, qbase, i)] < 0) return 0ull;
     tb = i;
   }
   return ((uint64_t)f2key(s) << 32) | (uint64_t)(0xFFFFFFFFu - tb);
@@ -67,8 +74,8 @@ __device__ __forceinline__ bool key_before(const SelParams& p, int64_t qbase, ui
     const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
     if (sa != sb) return sa > sb;
     if (a == 0ull || b == 0ull) return a > b;
-    const int64_t ia = p.ids64[entry_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)a)];
-    const int64_t ib = p.ids64[entry_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)b)];
+    const int64_t ia = p.ids64[id_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)a)];
+    const int64_t ib = p.ids64[id_addr(p, qbase, 0xFFFFFFFFu - (uint32_t)b)];
     return ia < ib;
   } else {
     return a > b;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
     if (i < kk && key != 0ull) {
       s = key2f((uint32_t)(key >> 32));
       const uint32_t tb = 0xFFFFFFFFu - (uint32_t)key;
-      if constexpr (MODE == SEL_MERGE64) id = p.ids64[entry_addr(p, qbase, tb)];
+      if constexpr (MODE == SEL_MERGE64) id = p.ids64[id_addr(p, qbase, tb)];
       else id = (int64_t)tb;
     }
     os[i] = s;

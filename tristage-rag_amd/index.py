@@ -56,6 +56,8 @@ def _stream_ptr(device_index: int) -> int:
 class FlatIPIndex:
     """Exact inner-product index resident in MI355X HBM."""
 
+    supports_out = True  # search(..., out=(D, I)) writes into caller tensors
+
     def __init__(self, d: int, dtype: str = "f32", device: int = 0):
         if dtype not in _NAME_TO_DTYPE:
             raise ValueError(f"unknown storage dtype {dtype!r}")
@@ -124,14 +126,15 @@ class FlatIPIndex:
                                           None))
         return None
 
-    def search(self, q, k: int, exact_dense: bool = False, async_: bool = False):
+    def search(self, q, k: int, exact_dense: bool = False, async_: bool = False, out=None):
         """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
         numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out.
 
         ``async_=True`` (CUDA tensors only): the work is only enqueued on the current
         stream and the output tensors are returned at once; they are complete and
         verified after :meth:`finish`.  Batches issued this way run back to back on
-        the GPU without a host round trip between them."""
+        the GPU without a host round trip between them.
+        ``out=(D, I)``: CUDA tensors [B,k] float32 / int64 to write into."""
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
@@ -148,8 +151,14 @@ class FlatIPIndex:
                 raise ValueError(f"expected [B, {self.d}] queries, got {tuple(q.shape)}")
             q = q.contiguous()
             B = q.shape[0]
-            D = torch.empty((B, k), dtype=torch.float32, device=q.device)
-            I = torch.empty((B, k), dtype=torch.int64, device=q.device)
+            if out is not None:
+                D, I = out
+                if (D.shape != (B, k) or I.shape != (B, k) or D.dtype != torch.float32 or
+                        I.dtype != torch.int64 or not D.is_contiguous() or not I.is_contiguous()):
+                    raise ValueError("out must be contiguous (float32[B,k], int64[B,k]) CUDA tensors")
+            else:
+                D = torch.empty((B, k), dtype=torch.float32, device=q.device)
+                I = torch.empty((B, k), dtype=torch.int64, device=q.device)
             self._search_raw(q.data_ptr(), B, _tensor_dtype(q), k, D.data_ptr(), I.data_ptr(),
                              flags, _stream_ptr(self.device))
             if async_:
@@ -246,6 +255,25 @@ def merge_topk(scores, ids, k: Optional[int] = None):
                                  R, B, kk, ctypes.c_void_p(out_s.data_ptr()),
                                  ctypes.c_void_p(out_i.data_ptr()), dev,
                                  ctypes.c_void_p(_stream_ptr(dev))))
+    return out_s, out_i
+
+
+def merge_topk_packed(gathered, R: int, B: int, k: int):
+    """Merge straight out of an all-gather buffer: `gathered` is a uint8 CUDA tensor of R
+    blocks, each = float32 scores [B,k] followed by int64 ids [B,k] (12*B*k bytes)."""
+    torch = _torch()
+    lib = _lib.load()
+    nbytes = 12 * B * k
+    if gathered.dtype != torch.uint8 or gathered.numel() != R * nbytes or (B * k) % 2:
+        raise ValueError("bad packed buffer")
+    out_s = torch.empty((B, k), dtype=torch.float32, device=gathered.device)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=gathered.device)
+    base = gathered.data_ptr()
+    dev = gathered.device.index
+    _lib.check(lib.ts_merge_topk_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * B * k), R, B, k,
+                                         nbytes // 4, nbytes // 8, ctypes.c_void_p(out_s.data_ptr()),
+                                         ctypes.c_void_p(out_i.data_ptr()), dev,
+                                         ctypes.c_void_p(_stream_ptr(dev))))
     return out_s, out_i
 
 

@@ -57,9 +57,11 @@ class ShardedFlatIPIndex:
             local_index.reserve(max(self.hi - self.lo, 1))
         self.local_index = local_index
         self.local_index.set_id_offset(self.lo)
+        self.merge_packed_fn = None
         if merge_fn is None:
-            from .index import merge_topk
+            from .index import merge_topk, merge_topk_packed
             merge_fn = merge_topk
+            self.merge_packed_fn = merge_topk_packed   # reads the all-gather buffer in place
         self.merge_fn = merge_fn
         self._pending = []
         self.always_exchange = False  # tests: run the collective + merge even for one rank
@@ -90,21 +92,48 @@ class ShardedFlatIPIndex:
         import torch
         if async_ and len(self._pending) >= 48:
             self.finish()
+        B = q.shape[0]
+        # the local result is produced directly inside the buffer that is exchanged:
+        # [float32 scores | int64 ids] = 12*B*k bytes, no packing kernels
+        packed = self._packed_buffer(B, k, q.device)
+        D = packed[: 4 * B * k].view(torch.float32).view(B, k)
+        I = packed[4 * B * k:].view(torch.int64).view(B, k)
         if self.hi > self.lo:
-            D, I = (self.local_index.search(q, k, async_=True) if async_ else self.local_index.search(q, k))
-            if not torch.is_tensor(D):
-                D, I = torch.from_numpy(D), torch.from_numpy(I)
+            if getattr(self.local_index, "supports_out", False):
+                self.local_index.search(q, k, async_=async_, out=(D, I))
+            else:
+                d, i = self.local_index.search(q, k)
+                D.copy_(torch.as_tensor(d))
+                I.copy_(torch.as_tensor(i))
         else:  # an empty shard contributes only padding
-            B = q.shape[0]
-            D = torch.full((B, k), -3.4028234663852886e38, dtype=torch.float32, device=q.device)
-            I = torch.full((B, k), -1, dtype=torch.int64, device=q.device)
+            D.fill_(-3.4028234663852886e38)
+            I.fill_(-1)
         if self.world_size == 1 and not self.always_exchange:
             return D, I
-        Dg, Ig = self._all_gather(D, I)
-        out = self.merge_fn(Dg, Ig)
+        out = self._exchange_and_merge(packed, B, k)
         if async_:
-            self._pending.append((q, k, D, I, out))
+            self._pending.append((q, k, packed, out))
         return out
+
+    def _packed_buffer(self, B: int, k: int, device):
+        import torch
+        if (B * k) % 2:
+            raise ValueError("B*k must be even")
+        return torch.empty((12 * B * k,), dtype=torch.uint8, device=device)
+
+    def _exchange_and_merge(self, packed, B: int, k: int):
+        """ONE collective (all-gather of the packed partial results) + the merge kernel,
+        which reads the gathered buffer in place."""
+        import torch
+        flat = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8, device=packed.device)
+        self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
+        if self.merge_packed_fn is not None:
+            return self.merge_packed_fn(flat, self.world_size, B, k)
+        ns = 4 * B * k
+        blocks = flat.view(self.world_size, packed.numel())
+        Dg = blocks[:, :ns].contiguous().view(torch.float32).reshape(self.world_size, B, k)
+        Ig = blocks[:, ns:].contiguous().view(torch.int64).reshape(self.world_size, B, k)
+        return self.merge_fn(Dg, Ig)
 
     def finish(self):
         """Complete asynchronous searches on every rank.  If ANY rank had to repeat a
@@ -117,16 +146,15 @@ class ShardedFlatIPIndex:
         # the i-th pending entry of every rank is the same batch; local tickets are
         # consecutive, so "repeated" maps to positions from the end
         last = self._last_ticket()
-        flags = torch.zeros(len(self._pending), dtype=torch.int32, device=self._pending[0][4][0].device)
+        flags = torch.zeros(len(self._pending), dtype=torch.int32, device=self._pending[0][2].device)
         for t in redone_local:
             pos = len(self._pending) - 1 - (last - t)
             if 0 <= pos < len(self._pending):
                 flags[pos] = 1
         self._dist.all_reduce(flags, op=self._dist.ReduceOp.MAX, group=self.group)
         for pos in torch.nonzero(flags).flatten().tolist():
-            q, k, D, I, out = self._pending[pos]
-            Dg, Ig = self._all_gather(D, I)          # D, I were corrected in place by local finish()
-            Dn, In = self.merge_fn(Dg, Ig)
+            q, k, packed, out = self._pending[pos]   # packed was corrected in place by local finish()
+            Dn, In = self._exchange_and_merge(packed, q.shape[0], k)
             out[0].copy_(Dn)
             out[1].copy_(In)
         torch.cuda.current_stream().synchronize() if flags.is_cuda else None
@@ -135,17 +163,3 @@ class ShardedFlatIPIndex:
     def _last_ticket(self) -> int:
         li = self.local_index
         return int(li._lib.ts_index_last_ticket(li._h)) if hasattr(li, "_lib") else -1
-
-    def _all_gather(self, D, I):
-        """One collective: [scores | ids] packed as bytes -> [R, B, k] pair."""
-        import torch
-        B, k = D.shape
-        packed = torch.cat([D.contiguous().view(torch.uint8).reshape(-1),
-                            I.contiguous().view(torch.uint8).reshape(-1)])
-        flat = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8, device=packed.device)
-        self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
-        out = flat.view(self.world_size, packed.numel())
-        ns = B * k * 4
-        Dg = out[:, :ns].contiguous().view(torch.float32).reshape(self.world_size, B, k)
-        Ig = out[:, ns:].contiguous().view(torch.int64).reshape(self.world_size, B, k)
-        return Dg, Ig
