@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--stage2", default="random:modernbert")    # GTE-ModernColBERT backbone shape
     ap.add_argument("--stage3", default="random:minilm")        # ms-marco-MiniLM-L6 shape
     ap.add_argument("--cache", action="store_true", help="cache stage-2 token matrices per document")
+    ap.add_argument("--store", action="store_true",
+                    help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -39,7 +41,8 @@ def main():
                         log_file="/tmp/ts_pipeline.log", log_level="WARNING",
                         stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=False,
                         stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
-                        stage3_batch_size=64, stage2_cache_document_embeddings=args.cache)
+                        stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
+                        stage2_precompute_document_embeddings=args.store)
     p = RetrievalPipeline(config=pc)
     t0 = time.perf_counter()
     p.add_documents(docs)
@@ -60,7 +63,7 @@ def main():
         "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
-                   "stage2_token_cache": args.cache},
+                   "stage2_token_cache": args.cache, "stage2_token_store": args.store},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "data": "synthetic"}))

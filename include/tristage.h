@@ -152,6 +152,15 @@ int ts_maxsim(const void* q, int32_t Lq, const void* docs,
               const int32_t* doc_off, int32_t n_docs, int32_t H, int32_t dtype,
               int32_t mode, float* out, int32_t device, void* stream);
 
+/* Same scores for candidates that already live in a resident token store
+ * (token matrices computed once at add time instead of per query,
+ * reference src/stage2_rescorer.py:254-259): document i occupies rows
+ * [starts[i], starts[i]+lens[i]) of `store` [rows, H].  starts: device int64[n_docs],
+ * lens: device int32[n_docs].  No gather copy: the kernel reads the store in place. */
+int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, const int64_t* starts,
+                      const int32_t* lens, int32_t n_docs, int32_t H, int32_t dtype,
+                      int32_t mode, float* out, int32_t device, void* stream);
+
 /* ---- misc ---------------------------------------------------------------- */
 const char* ts_last_error(void);
 int ts_abi_version(void);

@@ -52,3 +52,9 @@ def oracle_maxsim(q, packed, off, mode="maxsim"):
 def oracle_merge(scores, ids):
     D, I = oracle.merge_topk(scores.cpu().numpy(), ids.cpu().numpy(), scores.shape[2])
     return torch.from_numpy(D), torch.from_numpy(I)
+
+
+def oracle_maxsim_indexed(q, store, starts, lens, mode="maxsim"):
+    st = store.detach().cpu().float().numpy()
+    docs = [st[int(a): int(a) + int(n)] for a, n in zip(starts.cpu().tolist(), lens.cpu().tolist())]
+    return torch.from_numpy(oracle.maxsim_scores(q.detach().cpu().float().numpy(), docs, mode))

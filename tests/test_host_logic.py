@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from doubles import OracleIndex, oracle_maxsim
+from doubles import OracleIndex, oracle_maxsim, oracle_maxsim_indexed
 from tristage_rag_amd.embedding_service import EmbeddingConfig, EmbeddingService
 from tristage_rag_amd.encoders import CrossEncoderModel, HashTokenizer, SentenceEncoder
 from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
@@ -359,3 +359,22 @@ def test_chunk_text_and_three_stage_system(encoder, tmp_path):
     assert set(r) == {"rank", "doc_id", "document", "final_score", "stage1_score", "stage2_score", "stage3_score"}
     assert r["rank"] == 1 and r["final_score"] == r["stage3_score"] == 1.0
     assert len(sys_.search_history) == 1
+
+
+def test_stage2_token_store_matches_reencoding():
+    cfg = Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=10, batch_size=2,
+                       precompute_document_embeddings=True)
+    sc = ColBERTScorer(cfg, maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed)
+    cands = [{"doc_id": 100 + i, "document": d} for i, d in enumerate(DOCS)]
+    plain = sc.rescore_candidates("neural attention", cands)          # store empty -> encode path
+    sc.index_documents(DOCS[:3], 100)
+    sc.index_documents(DOCS[3:], 103)                                  # appended in two calls
+    assert len(sc.token_store) == 5 and sc.token_store.rows == sum(sc.token_store.lens)
+    stored = sc.rescore_candidates("neural attention", cands[::-1])    # any candidate order
+    a = {x["doc_id"]: x["stage2_score"] for x in plain}
+    b = {x["doc_id"]: x["stage2_score"] for x in stored}
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k] == pytest.approx(b[k], abs=1e-5)                   # batch-padding noise only
+    mixed = sc.rescore_candidates("neural attention", cands + [{"doc_id": 999, "document": "not stored"}])
+    assert len(mixed) == 6                                             # unknown id -> encode path for all

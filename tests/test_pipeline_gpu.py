@@ -91,3 +91,30 @@ def test_bf16_pipeline_runs_and_ranks(tmp_path):
     assert s1[0]["doc_id"] == 7 and s1[0]["score"] > 0.99
     r2 = p.search(docs[7])                     # second time: stage-2 token matrices come from the cache
     assert [x["doc_id"] for x in r2["results"]] == [x["doc_id"] for x in r["results"]]
+
+
+def test_token_store_pipeline_equals_reencoding_pipeline(tmp_path):
+    """Stage 2 from the resident token store (filled at add_documents) vs re-encoding the
+    candidates per query (the reference's behaviour): same ranking, scores to 1e-3."""
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    docs = _corpus(400)
+    outs = []
+    for store in (False, True):
+        pc = PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                            device="cuda", cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / "i"),
+                            log_file=str(tmp_path / f"s{store}.log"), stage1_top_k=60, stage2_top_k=20,
+                            stage3_top_k=5, stage1_enable_bm25=False, stage2_use_fp16=False,
+                            save_intermediate_results=True, stage2_precompute_document_embeddings=store)
+        p = RetrievalPipeline(config=pc)
+        p.initialize_stages()
+        p.add_documents(docs[:250])
+        p.add_documents(docs[250:])
+        if store:
+            assert len(p.stage2.token_store) == len(docs)
+        outs.append([p.search(q) for q in ("neural network attention", "gpu memory", docs[5])])
+    for a, b in zip(*outs):
+        sa = {r["doc_id"]: r["stage2_score"] for r in a["stage2_results"]}
+        sb = {r["doc_id"]: r["stage2_score"] for r in b["stage2_results"]}
+        assert set(sa) == set(sb) or len(set(sa) ^ set(sb)) <= 2
+        for k in set(sa) & set(sb):
+            assert abs(sa[k] - sb[k]) < 1e-3

@@ -267,3 +267,22 @@ def test_filter_path_edge_shapes(n, d, k, B, dtype):
     assert idx.last_search_info()["path"] == "filter"
     check_topk(D, I, corpus, queries, k)
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_maxsim_indexed_reads_token_store_in_place(torch_mod, dtype):
+    torch = torch_mod
+    from tristage_rag_amd.index import maxsim, maxsim_indexed
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
+    rng = np.random.default_rng(4)
+    H, Lq = 128, 11
+    lens = rng.integers(1, 190, size=300)
+    store = oracle.quantize(rng.standard_normal((int(lens.sum()) + 50, H)).astype(np.float32), dtype)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]) + 17           # not at row 0
+    starts = np.minimum(starts, store.shape[0] - lens)
+    q = oracle.quantize(rng.standard_normal((Lq, H)).astype(np.float32), dtype)
+    pick = rng.permutation(300)[:120]                                    # arbitrary candidate order
+    got = maxsim_indexed(torch.from_numpy(q).cuda().to(tdt), torch.from_numpy(store).cuda().to(tdt),
+                         torch.from_numpy(starts[pick]).cuda(), torch.from_numpy(lens[pick].astype(np.int32)).cuda())
+    docs = [store[starts[i]: starts[i] + lens[i]] for i in pick]
+    np.testing.assert_allclose(got.cpu().numpy(), oracle.maxsim_scores(q, docs), atol=2e-6, rtol=0)

@@ -46,6 +46,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int32, c_void_p]),
     "ts_maxsim": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                             c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_maxsim_indexed": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                    c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "ts_last_error": (c_char_p, []),
     "ts_abi_version": (c_int32, []),
 }

@@ -162,5 +162,5 @@ int ts_launch_tau(const float* sample, int64_t ld, uint32_t n, uint32_t m,
 
 // ---------------------------------------------------------------- maxsim
 int ts_launch_maxsim(const void* q, int Lq, const void* docs,
-                     const int32_t* doc_off, int n_docs, int H, int dtype,
-                     int mode, float* out, hipStream_t stream);
+                     const int32_t* doc_off, const int64_t* starts, const int32_t* lens,
+                     int n_docs, int H, int dtype, int mode, float* out, hipStream_t stream);

@@ -690,5 +690,21 @@ extern "C" int ts_maxsim(const void* q, int32_t Lq, const void* docs, const int3
   }
   DeviceGuard g(device);
   if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
-  return ts_launch_maxsim(q, Lq, docs, doc_off, n_docs, H, dtype, mode, out, (hipStream_t)stream);
+  return ts_launch_maxsim(q, Lq, docs, doc_off, nullptr, nullptr, n_docs, H, dtype, mode, out,
+                          (hipStream_t)stream);
+}
+
+extern "C" int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, const int64_t* starts,
+                                 const int32_t* lens, int32_t n_docs, int32_t H, int32_t dtype,
+                                 int32_t mode, float* out, int32_t device, void* stream) {
+  if (n_docs == 0) return TS_OK;
+  if (!q || !store || !starts || !lens || !out || Lq < 0 || n_docs < 0 || H <= 0 || !dtype_ok(dtype) ||
+      (mode != 0 && mode != 1)) {
+    ts_set_error("bad arguments to maxsim_indexed");
+    return TS_ERR_INVALID;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  return ts_launch_maxsim(q, Lq, store, nullptr, starts, lens, n_docs, H, dtype, mode, out,
+                          (hipStream_t)stream);
 }

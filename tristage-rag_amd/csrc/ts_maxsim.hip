@@ -59,7 +59,8 @@ __device__ __forceinline__ int ms_acc_row(int r, int lane) {
 template <typename T>
 __global__ __launch_bounds__(MS_THREADS) void maxsim_kernel(
     const T* __restrict__ q, int Lq, const T* __restrict__ docs,
-    const int32_t* __restrict__ doc_off, int H, int mode, float* __restrict__ out) {
+    const int32_t* __restrict__ doc_off, const int64_t* __restrict__ starts,
+    const int32_t* __restrict__ lens, int H, int mode, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* msc = reinterpret_cast<float*>(smem);     // [nqt*32] final m_i
   float* pm = msc + ((Lq + 31) / 32) * 32;         // [MS_WAVES][32] per-wave row maxima
@@ -70,8 +71,10 @@ __global__ __launch_bounds__(MS_THREADS) void maxsim_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int d0 = doc_off[doc];
-  const int Ld = doc_off[doc + 1] - d0;
+  // packed candidates (doc_off prefix sums) or rows [start, start+len) of a resident
+  // token store (the stage-2 cache: no gather copy, the kernel reads in place)
+  const int64_t d0 = starts ? starts[doc] : (int64_t)doc_off[doc];
+  const int Ld = starts ? lens[doc] : (doc_off[doc + 1] - doc_off[doc]);
   if (Ld <= 0 || Lq <= 0) {
     // reference: a candidate that cannot be scored keeps 0.0
     // (src/stage2_rescorer.py:285-291)
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(MS_THREADS) void maxsim_kernel(
 
 template <typename T>
 static int launch_maxsim_t(const T* q, int Lq, const T* docs, const int32_t* off,
+                           const int64_t* starts, const int32_t* lens,
                            int n_docs, int H, int mode, float* out, hipStream_t s) {
   const size_t lds = (size_t)(((Lq + 31) / 32) * 32 + MS_WAVES * 32 + 32 + MS_THREADS) * 4;
   if (lds > 60 * 1024) {
@@ -213,19 +217,20 @@ static int launch_maxsim_t(const T* q, int Lq, const T* docs, const int32_t* off
     return TS_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(maxsim_kernel<T>, dim3(n_docs), dim3(MS_THREADS), lds, s, q, Lq,
-                     docs, off, H, mode, out);
+                     docs, off, starts, lens, H, mode, out);
   TS_HIP(hipGetLastError());
   return TS_OK;
 }
 
 int ts_launch_maxsim(const void* q, int Lq, const void* docs, const int32_t* doc_off,
+                     const int64_t* starts, const int32_t* lens,
                      int n_docs, int H, int dtype, int mode, float* out,
                      hipStream_t stream) {
   if (n_docs <= 0) return TS_OK;
   switch (dtype) {
-    case TS_F32: return launch_maxsim_t<float>((const float*)q, Lq, (const float*)docs, doc_off, n_docs, H, mode, out, stream);
-    case TS_F16: return launch_maxsim_t<_Float16>((const _Float16*)q, Lq, (const _Float16*)docs, doc_off, n_docs, H, mode, out, stream);
-    case TS_BF16: return launch_maxsim_t<__bf16>((const __bf16*)q, Lq, (const __bf16*)docs, doc_off, n_docs, H, mode, out, stream);
+    case TS_F32: return launch_maxsim_t<float>((const float*)q, Lq, (const float*)docs, doc_off, starts, lens, n_docs, H, mode, out, stream);
+    case TS_F16: return launch_maxsim_t<_Float16>((const _Float16*)q, Lq, (const _Float16*)docs, doc_off, starts, lens, n_docs, H, mode, out, stream);
+    case TS_BF16: return launch_maxsim_t<__bf16>((const __bf16*)q, Lq, (const __bf16*)docs, doc_off, starts, lens, n_docs, H, mode, out, stream);
   }
   ts_set_error("bad dtype %d", dtype);
   return TS_ERR_INVALID;

@@ -301,3 +301,29 @@ def maxsim(q, docs, doc_offsets, mode: str = "maxsim"):
                              ctypes.c_void_p(out.data_ptr()), dev,
                              ctypes.c_void_p(_stream_ptr(dev))))
     return out
+
+
+def maxsim_indexed(q, store, starts, lens, mode: str = "maxsim"):
+    """Stage-2 scores for candidates that live in a resident token store: document i
+    is rows [starts[i], starts[i]+lens[i]) of ``store`` [rows, H] (CUDA tensors; starts
+    int64, lens int32).  The kernel reads the store in place."""
+    torch = _torch()
+    lib = _lib.load()
+    if q.dtype != store.dtype:
+        q = q.to(store.dtype)
+    q = q.contiguous()
+    if not store.is_contiguous():
+        raise ValueError("token store must be contiguous")
+    starts = starts.to(device=q.device, dtype=torch.int64).contiguous()
+    lens = lens.to(device=q.device, dtype=torch.int32).contiguous()
+    n = starts.numel()
+    out = torch.empty((n,), dtype=torch.float32, device=q.device)
+    if n == 0:
+        return out
+    dev = q.device.index
+    _lib.check(lib.ts_maxsim_indexed(ctypes.c_void_p(q.data_ptr()), q.shape[0],
+                                     ctypes.c_void_p(store.data_ptr()), ctypes.c_void_p(starts.data_ptr()),
+                                     ctypes.c_void_p(lens.data_ptr()), n, q.shape[1], _tensor_dtype(q),
+                                     0 if mode == "maxsim" else 1, ctypes.c_void_p(out.data_ptr()), dev,
+                                     ctypes.c_void_p(_stream_ptr(dev))))
+    return out

@@ -66,6 +66,7 @@ class PipelineConfig:
     # ---- additive (MI355X) ----
     stage1_index_dtype: str = "f32"          # corpus storage on the GPU: f32 | f16 | bf16
     stage2_cache_document_embeddings: bool = False
+    stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
 
 
 # (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
@@ -156,7 +157,8 @@ class RetrievalPipeline:
                 max_seq_length=c.stage2_max_seq_length, batch_size=c.stage2_batch_size,
                 top_k_candidates=c.stage2_top_k, use_fp16=c.stage2_use_fp16,
                 scoring_method=c.stage2_scoring_method,
-                cache_document_embeddings=c.stage2_cache_document_embeddings))
+                cache_document_embeddings=c.stage2_cache_document_embeddings,
+                precompute_document_embeddings=c.stage2_precompute_document_embeddings))
             self.logger.info("Stage 2 initialized")
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
@@ -173,7 +175,10 @@ class RetrievalPipeline:
             self.initialize_stages()
         self.logger.info(f"Adding {len(documents)} documents to pipeline")
         try:
+            first_id = len(self.stage1.documents)
             self.stage1.add_documents(documents, metadata)
+            if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
+                self.stage2.index_documents(list(documents), first_id)
         except Exception as e:
             self.logger.error(f"Error adding documents: {e}")
             raise

@@ -38,21 +38,69 @@ class Stage2Config:
     scoring_method: str = "maxsim"  # "maxsim" or "colbert"
     use_gpu_if_available: bool = True
     # additive
-    cache_document_embeddings: bool = False
+    cache_document_embeddings: bool = False      # memoise token matrices per document text
+    precompute_document_embeddings: bool = False  # resident token store filled at add time
+
+
+class TokenStore:
+    """Token matrices of indexed documents, resident on the GPU as one [rows, H]
+    tensor plus per-document (start, length); grown geometrically.  Stage 2 then
+    reads candidates in place (ts_maxsim_indexed) instead of re-encoding them for
+    every query (reference src/stage2_rescorer.py:254-259)."""
+
+    def __init__(self):
+        self.data: Optional[torch.Tensor] = None
+        self.rows = 0
+        self.starts: List[int] = []
+        self.lens: List[int] = []
+        self._starts_dev: Optional[torch.Tensor] = None
+        self._lens_dev: Optional[torch.Tensor] = None
+
+    def __len__(self) -> int:
+        return len(self.starts)
+
+    def append(self, mats: List[torch.Tensor]) -> None:
+        if not mats:
+            return
+        add = sum(int(m.shape[0]) for m in mats)
+        H = int(mats[0].shape[1])
+        if self.data is None or self.rows + add > self.data.shape[0]:
+            cap = max(self.rows + add, int(1.5 * (self.data.shape[0] if self.data is not None else 0)), 1024)
+            new = torch.empty((cap, H), dtype=mats[0].dtype, device=mats[0].device)
+            if self.data is not None and self.rows:
+                new[: self.rows].copy_(self.data[: self.rows])
+            self.data = new
+        for m in mats:
+            n = int(m.shape[0])
+            self.data[self.rows: self.rows + n].copy_(m)
+            self.starts.append(self.rows)
+            self.lens.append(n)
+            self.rows += n
+        self._starts_dev = None
+
+    def device_tables(self):
+        if self._starts_dev is None:
+            dev = self.data.device
+            self._starts_dev = torch.tensor(self.starts, dtype=torch.int64, device=dev)
+            self._lens_dev = torch.tensor(self.lens, dtype=torch.int32, device=dev)
+        return self._starts_dev, self._lens_dev
 
 
 class ColBERTScorer:
     """ColBERT-style MaxSim scoring for multi-vector retrieval."""
 
     def __init__(self, config: Stage2Config, model: Any = None, tokenizer: Any = None,
-                 maxsim_fn: Optional[Callable] = None):
+                 maxsim_fn: Optional[Callable] = None, maxsim_indexed_fn: Optional[Callable] = None):
         self.config = config
         self.logger = logging.getLogger(__name__)
         self.model = model
         self.tokenizer = tokenizer
         self.device = self._get_device()
         self._maxsim_fn = maxsim_fn
+        self._maxsim_indexed_fn = maxsim_indexed_fn
         self._doc_cache: Dict[str, torch.Tensor] = {}
+        self.token_store = TokenStore()        # filled by index_documents()
+        self._store_slot: Dict[int, int] = {}  # pipeline doc_id -> slot in the store
         self._load_model()
 
     def _get_device(self) -> str:
@@ -174,14 +222,45 @@ class ColBERTScorer:
         scores = fn(q, packed, off.to(q.device), mode or self.config.scoring_method)
         return [float(x) for x in scores.detach().cpu().tolist()]
 
+    def index_documents(self, documents: List[str], first_doc_id: int) -> None:
+        """Encode `documents` once and keep their token matrices on the GPU; document j
+        gets pipeline id first_doc_id + j (the doc_id stage 1 reports)."""
+        bs = max(self.config.batch_size, 1)
+        for s in range(0, len(documents), 8 * bs):
+            chunk = documents[s: s + 8 * bs]
+            mats = self.encode_documents_batch(chunk)
+            base = len(self.token_store)
+            self.token_store.append([m.contiguous() for m in mats])
+            for j in range(len(chunk)):
+                self._store_slot[first_doc_id + s + j] = base + j
+
+    def _score_from_store(self, query_embeddings: torch.Tensor, candidates: List[Dict[str, Any]]):
+        """Scores straight from the resident token store, or None if a candidate is not in it."""
+        if not len(self.token_store):
+            return None
+        slots = [self._store_slot.get(c.get("doc_id"), -1) for c in candidates]
+        if min(slots) < 0:
+            return None
+        starts_all, lens_all = self.token_store.device_tables()
+        sel = torch.tensor(slots, dtype=torch.int64, device=starts_all.device)
+        q = query_embeddings.squeeze(0).to(self.token_store.data.dtype).contiguous()
+        fn = self._maxsim_indexed_fn
+        if fn is None:
+            from .index import maxsim_indexed  # HIP kernel; raises without the library or a GPU
+            fn = maxsim_indexed
+        scores = fn(q, self.token_store.data, starts_all[sel], lens_all[sel], self.config.scoring_method)
+        return [float(x) for x in scores.detach().cpu().tolist()]
+
     def rescore_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         if not candidates:
             return []
         self.logger.info(f"Rescoring {len(candidates)} candidates with Stage 2")
         query_embeddings = self.encode_query(query)
-        documents = [c["document"] for c in candidates]
-        doc_embeddings_list = self.encode_documents_batch(documents)
-        scores = self.score_all(query_embeddings, doc_embeddings_list)
+        scores = self._score_from_store(query_embeddings, candidates)
+        if scores is None:
+            documents = [c["document"] for c in candidates]
+            doc_embeddings_list = self.encode_documents_batch(documents)
+            scores = self.score_all(query_embeddings, doc_embeddings_list)
         scored = []
         for cand, s in zip(candidates, scores):
             u = cand.copy()
