@@ -161,6 +161,24 @@ int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, const int64_
                       const int32_t* lens, int32_t n_docs, int32_t H, int32_t dtype,
                       int32_t mode, float* out, int32_t device, void* stream);
 
+/* ---- BM25 (the lexical half of stage 1) ---------------------------------------
+ * replaces BM25Index.search (reference src/stage1_retriever.py:103-112, called at
+ * :385-388): same float64 arithmetic and ordering (score desc, doc id asc), but the
+ * postings live in HBM (CSR) and a query touches only its terms' postings.
+ * ts_bm25_set_index takes HOST arrays: term_off[V+1], post_doc/post_tf[nnz] sorted
+ * by term, idf[V], len_norm[N] = k1*(1-b+b*len/avg), k1p1 = k1+1.
+ * ts_bm25_search: term_ids = query tokens as vocabulary ids in query order (host);
+ * writes up to k (score, doc) pairs to HOST arrays; *n_out < k means all documents
+ * with a non-zero score were returned (the rest score exactly 0.0).            */
+typedef struct ts_bm25 ts_bm25;
+int ts_bm25_create(int32_t device, ts_bm25** out);
+int ts_bm25_destroy(ts_bm25* h);
+int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, const int64_t* term_off,
+                      const int32_t* post_doc, const float* post_tf, const double* idf,
+                      const double* len_norm, double k1p1);
+int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
+                   double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream);
+
 /* ---- misc ---------------------------------------------------------------- */
 const char* ts_last_error(void);
 int ts_abi_version(void);

@@ -48,6 +48,12 @@ SIGNATURES = {
                             c_int32, c_void_p, c_int32, c_void_p]),
     "ts_maxsim_indexed": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_bm25_create": (c_int32, [c_int32, POINTER(c_void_p)]),
+    "ts_bm25_destroy": (c_int32, [c_void_p]),
+    "ts_bm25_set_index": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, ctypes.c_double]),
+    "ts_bm25_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                 POINTER(c_int32), c_void_p]),
     "ts_last_error": (c_char_p, []),
     "ts_abi_version": (c_int32, []),
 }

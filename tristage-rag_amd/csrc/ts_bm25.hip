@@ -1,0 +1,317 @@
+// BM25 scoring on the GPU — the lexical half of the reference's default stage 1
+// (BM25Index, reference src/stage1_retriever.py:35-112, used at :385-400 and fused
+// with the dense list by RRF / weighted fusion).  The reference scores every
+// document with a per-document Python loop (O(N*|q|) per query); here the
+// postings live in HBM as CSR and a query touches only the postings of its terms.
+//
+// Arithmetic = the reference's, in float64:  for query tokens in order,
+//     acc[d] += idf[t] * (tf*(k1+1)) / (tf + k1*(1 - b + b*len[d]/avg_len))
+// One launch per query token (a token's postings hit distinct documents, so no
+// atomics on the accumulator and every document receives its additions in query
+// order: bit-identical sums).  The first launch that touches a document appends
+// it to the query's "touched" list; the top-k (score desc, doc id asc — the
+// reference's stable descending sort) is selected from that list by a 96-bit
+// MSB-first radix select (64 score bits, then 32 id bits) and a bitonic sort of
+// the k survivors.  Documents nobody touched score 0.0 and are filled in by the
+// host in ascending id order when fewer than k documents were touched.
+#include "ts_common.h"
+
+#include <new>
+
+#define BM_SEL_THREADS 1024
+#define BM_MAX_K 2048
+
+struct ts_bm25 {
+  int device = 0;
+  int64_t N = 0, V = 0, nnz = 0;
+  double k1p1 = 2.2;
+  int32_t* post_doc = nullptr;
+  float* post_tf = nullptr;
+  double* idf = nullptr;       // [V]
+  double* len_norm = nullptr;  // [N]  k1*(1-b+b*len/avg)
+  double* acc = nullptr;       // [N], all zero between queries
+  int32_t* touched = nullptr;  // [N]
+  uint32_t* counters = nullptr;  // [0] n_touched
+  double* out_s = nullptr;     // [BM_MAX_K]
+  int32_t* out_i = nullptr;    // [BM_MAX_K]
+  int64_t* term_off = nullptr;  // host copy [V+1]
+  double* idf_host = nullptr;
+};
+
+namespace {
+struct Guard {
+  int prev = -1;
+  explicit Guard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~Guard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
+__global__ void bm25_accumulate(const int32_t* __restrict__ post_doc, const float* __restrict__ post_tf,
+                                int64_t off, int64_t df, double idf, double k1p1,
+                                const double* __restrict__ len_norm, double* __restrict__ acc,
+                                int32_t* __restrict__ touched, uint32_t* __restrict__ n_touched) {
+  // no fused multiply-add here: the reference computes idf*(num/den) and the running
+  // sum with one rounding per operation (CPython floats), and hipcc contracts by default
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= df) return;
+  const int32_t d = post_doc[off + i];
+  const double tf = (double)post_tf[off + i];
+  const double c = idf * ((tf * k1p1) / (tf + len_norm[d]));
+  const double old = acc[d];
+  acc[d] = old + c;
+  if (old == 0.0) touched[atomicAdd(n_touched, 1u)] = d;  // contributions are > 0: first touch
+}
+
+__global__ void bm25_reset(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
+                           double* __restrict__ acc) {
+  const uint32_t n = *n_touched;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc[touched[i]] = 0.0;
+}
+
+__device__ __forceinline__ uint64_t d2key(double v) {  // orderable; scores are >= 0 but stay general
+  uint64_t u = __builtin_bit_cast(uint64_t, v + 0.0);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// digit `pass` (0..11) of the 96-bit key (score key, then ~doc so that smaller ids rank higher)
+__device__ __forceinline__ uint32_t key_digit(uint64_t sk, uint32_t dk, int pass) {
+  return pass < 8 ? (uint32_t)(sk >> (56 - 8 * pass)) & 0xFFu : (dk >> (24 - 8 * (pass - 8))) & 0xFFu;
+}
+
+__device__ __forceinline__ bool prefix_match(uint64_t sk, uint32_t dk, uint64_t psk, uint32_t pdk, int passes) {
+  if (passes == 0) return true;
+  if (passes <= 8) return passes == 8 ? sk == psk : (sk >> (64 - 8 * passes)) == (psk >> (64 - 8 * passes));
+  if (sk != psk) return false;
+  const int b = 8 * (passes - 8);
+  return b == 32 ? dk == pdk : (dk >> (32 - b)) == (pdk >> (32 - b));
+}
+
+// one vote per (thread, key); waves whose lanes agree on the bin add once (the top
+// bytes of the score key are shared by almost all documents)
+__device__ __forceinline__ void bm_vote(uint32_t* hist, bool in, uint32_t digit, int tid) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+  if (m == 0ull) return;
+  const int src = __builtin_ctzll(m);
+  const uint32_t d0 = (uint32_t)__shfl((int)digit, src, 64);
+  const unsigned long long same = __builtin_amdgcn_ballot_w64(in && digit == d0);
+  if (same == m) {
+    if ((tid & 63) == src) atomicAdd(&hist[d0], (uint32_t)__builtin_popcountll(m));
+  } else if (in) {
+    atomicAdd(&hist[digit], 1u);
+  }
+}
+
+__device__ __forceinline__ bool key_ge(uint64_t sk, uint32_t dk, uint64_t tsk, uint32_t tdk) {
+  return sk > tsk || (sk == tsk && dk >= tdk);
+}
+
+// one workgroup: exact top-k of the touched documents
+__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_select(const int32_t* __restrict__ touched,
+                                                              const uint32_t* __restrict__ n_touched,
+                                                              const double* __restrict__ acc, int k,
+                                                              double* __restrict__ out_s,
+                                                              int32_t* __restrict__ out_i,
+                                                              uint32_t* __restrict__ n_out) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh[8];
+  __shared__ uint64_t ssk[BM_MAX_K];
+  __shared__ uint32_t sdk[BM_MAX_K];
+  const int tid = threadIdx.x;
+  const uint32_t n = *n_touched;
+  const uint32_t kk = (uint32_t)k < n ? (uint32_t)k : n;
+  if (tid == 0) *n_out = kk;
+  if (kk == 0) return;
+  uint64_t psk = 0;
+  uint32_t pdk = 0;
+  int passes = 0;
+  uint32_t krem = kk;
+  bool whole = (n <= kk);  // everything is wanted: skip the select
+  if (!whole) {
+    for (int pass = 0; pass < 12; ++pass) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t base = 0; base < n; base += BM_SEL_THREADS) {  // wave-uniform trip count
+        const uint32_t i = base + tid;
+        const int32_t d = (i < n) ? touched[i] : 0;
+        const uint64_t sk = (i < n) ? d2key(acc[d]) : 0ull;
+        const uint32_t dk = ~(uint32_t)d;
+        bm_vote(hist, (i < n) && prefix_match(sk, dk, psk, pdk, passes), key_digit(sk, dk, pass), tid);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t cum = 0;
+        int dg = 255;
+        for (; dg > 0; --dg) {
+          if (cum + hist[dg] >= krem) break;
+          cum += hist[dg];
+        }
+        sh[0] = (uint32_t)dg;
+        sh[1] = krem - cum;
+        sh[2] = (hist[dg] == krem - cum) ? 1u : 0u;
+      }
+      __syncthreads();
+      const uint32_t dg = sh[0];
+      krem = sh[1];
+      if (pass < 8) psk |= (uint64_t)dg << (56 - 8 * pass);
+      else pdk |= dg << (24 - 8 * (pass - 8));
+      passes = pass + 1;
+      const bool done = sh[2] != 0;
+      __syncthreads();
+      if (done) break;
+    }
+  }
+  // survivors: key >= threshold prefix (lower bits zero)
+  if (tid == 0) sh[3] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += BM_SEL_THREADS) {
+    const int32_t d = touched[i];
+    const uint64_t sk = d2key(acc[d]);
+    const uint32_t dk = ~(uint32_t)d;
+    if (whole || key_ge(sk, dk, psk, pdk)) {
+      const uint32_t pos = atomicAdd(&sh[3], 1u);
+      if (pos < BM_MAX_K) { ssk[pos] = sk; sdk[pos] = dk; }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = sh[3] < BM_MAX_K ? sh[3] : BM_MAX_K;
+  uint32_t P = 2;
+  while (P < cnt) P <<= 1;
+  for (uint32_t i = cnt + tid; i < P; i += BM_SEL_THREADS) { ssk[i] = 0; sdk[i] = 0; }
+  __syncthreads();
+  for (uint32_t size = 2; size <= P; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < (P >> 1); t += BM_SEL_THREADS) {
+        const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint64_t a = ssk[i], b = ssk[j];
+        const uint32_t ad = sdk[i], bd = sdk[j];
+        const bool a_before_b = a > b || (a == b && ad > bd);
+        const bool b_before_a = b > a || (a == b && bd > ad);
+        if (desc ? b_before_a : a_before_b) { ssk[i] = b; ssk[j] = a; sdk[i] = bd; sdk[j] = ad; }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < kk && i < cnt; i += BM_SEL_THREADS) {
+    const int32_t d = (int32_t)~sdk[i];
+    out_i[i] = d;
+    out_s[i] = acc[d];
+  }
+}
+
+extern "C" int ts_bm25_create(int32_t device, ts_bm25** out) {
+  if (!out) { ts_set_error("out is null"); return TS_ERR_INVALID; }
+  *out = nullptr;
+  int ndev = 0;
+  TS_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { ts_set_error("device %d not present", device); return TS_ERR_INVALID; }
+  ts_bm25* h = new (std::nothrow) ts_bm25();
+  if (!h) { ts_set_error("out of host memory"); return TS_ERR_OOM; }
+  h->device = device;
+  *out = h;
+  return TS_OK;
+}
+
+static void bm25_free(ts_bm25* h) {
+  void* bufs[] = {h->post_doc, h->post_tf, h->idf, h->len_norm, h->acc, h->touched, h->counters, h->out_s, h->out_i};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  h->post_doc = nullptr; h->post_tf = nullptr; h->idf = nullptr; h->len_norm = nullptr; h->acc = nullptr;
+  h->touched = nullptr; h->counters = nullptr; h->out_s = nullptr; h->out_i = nullptr;
+  delete[] h->term_off; h->term_off = nullptr;
+  delete[] h->idf_host; h->idf_host = nullptr;
+}
+
+extern "C" int ts_bm25_destroy(ts_bm25* h) {
+  if (!h) return TS_OK;
+  Guard g(h->device);
+  (void)hipDeviceSynchronize();
+  bm25_free(h);
+  delete h;
+  return TS_OK;
+}
+
+// All pointers are host memory.  term_off[V+1] (CSR), post_doc/post_tf[nnz] sorted by
+// term, idf[V], len_norm[N] = k1*(1-b+b*len/avg), k1p1 = k1+1.
+extern "C" int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, const int64_t* term_off,
+                                 const int32_t* post_doc, const float* post_tf, const double* idf,
+                                 const double* len_norm, double k1p1) {
+  if (!h || N < 0 || V < 0 || nnz < 0 || N >= (1LL << 31) || (nnz && (!term_off || !post_doc || !post_tf)) ||
+      (V && !idf) || (N && !len_norm)) {
+    ts_set_error("bad arguments to bm25_set_index");
+    return TS_ERR_INVALID;
+  }
+  Guard g(h->device);
+  bm25_free(h);
+  h->N = N; h->V = V; h->nnz = nnz; h->k1p1 = k1p1;
+  h->term_off = new (std::nothrow) int64_t[V + 1];
+  h->idf_host = new (std::nothrow) double[V > 0 ? V : 1];
+  if (!h->term_off || !h->idf_host) { ts_set_error("out of host memory"); return TS_ERR_OOM; }
+  for (int64_t i = 0; i <= V; ++i) h->term_off[i] = term_off ? term_off[i] : 0;
+  for (int64_t i = 0; i < V; ++i) h->idf_host[i] = idf[i];
+  const size_t n1 = (size_t)(N > 0 ? N : 1), z1 = (size_t)(nnz > 0 ? nnz : 1);
+  TS_HIP(hipMalloc((void**)&h->post_doc, z1 * 4));
+  TS_HIP(hipMalloc((void**)&h->post_tf, z1 * 4));
+  TS_HIP(hipMalloc((void**)&h->len_norm, n1 * 8));
+  TS_HIP(hipMalloc((void**)&h->acc, n1 * 8));
+  TS_HIP(hipMalloc((void**)&h->touched, n1 * 4));
+  TS_HIP(hipMalloc((void**)&h->counters, 64));
+  TS_HIP(hipMalloc((void**)&h->out_s, BM_MAX_K * 8));
+  TS_HIP(hipMalloc((void**)&h->out_i, BM_MAX_K * 4));
+  if (nnz) {
+    TS_HIP(hipMemcpy(h->post_doc, post_doc, (size_t)nnz * 4, hipMemcpyHostToDevice));
+    TS_HIP(hipMemcpy(h->post_tf, post_tf, (size_t)nnz * 4, hipMemcpyHostToDevice));
+  }
+  if (N) TS_HIP(hipMemcpy(h->len_norm, len_norm, (size_t)N * 8, hipMemcpyHostToDevice));
+  TS_HIP(hipMemset(h->acc, 0, n1 * 8));
+  TS_HIP(hipMemset(h->counters, 0, 64));
+  return TS_OK;
+}
+
+// term_ids: the query's tokens mapped to vocabulary ids, in query order (unknown
+// tokens dropped, repeats kept).  Writes up to k (score, doc) pairs, best first;
+// *n_out < k means every document with a non-zero score is in the output.
+extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
+                              double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream) {
+  if (!h || !out_scores || !out_ids || !n_out || n_terms < 0 || k <= 0 || (n_terms && !term_ids)) {
+    ts_set_error("bad arguments to bm25_search");
+    return TS_ERR_INVALID;
+  }
+  if (k > BM_MAX_K) { ts_set_error("bm25 top_k %d exceeds %d", k, BM_MAX_K); return TS_ERR_UNSUPPORTED; }
+  *n_out = 0;
+  if (h->N == 0 || n_terms == 0) return TS_OK;
+  Guard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_terms; ++i) {
+    const int32_t t = term_ids[i];
+    if (t < 0 || t >= h->V) { ts_set_error("term id %d out of range", t); return TS_ERR_INVALID; }
+    const int64_t off = h->term_off[t], df = h->term_off[t + 1] - off;
+    if (df <= 0) continue;
+    const int64_t blocks = (df + 255) / 256;
+    hipLaunchKernelGGL(bm25_accumulate, dim3((unsigned)blocks), dim3(256), 0, s, h->post_doc, h->post_tf,
+                       off, df, h->idf_host[t], h->k1p1, h->len_norm, h->acc, h->touched, h->counters);
+  }
+  hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->touched, h->counters, h->acc, k,
+                     h->out_s, h->out_i, h->counters + 1);
+  TS_HIP(hipGetLastError());
+  uint32_t cnt[2] = {0, 0};
+  static thread_local int32_t ids32[BM_MAX_K];
+  TS_HIP(hipMemcpyAsync(cnt, h->counters, 8, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipMemcpyAsync(out_scores, h->out_s, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipMemcpyAsync(ids32, h->out_i, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
+  TS_HIP(hipMemsetAsync(h->counters, 0, 8, s));
+  TS_HIP(hipStreamSynchronize(s));
+  const int32_t n = (int32_t)cnt[1];
+  for (int32_t i = 0; i < n; ++i) out_ids[i] = ids32[i];
+  *n_out = n;
+  return TS_OK;
+}

@@ -65,6 +65,7 @@ class PipelineConfig:
     max_memory_usage_gb: float = 4.0
     # ---- additive (MI355X) ----
     stage1_index_dtype: str = "f32"          # corpus storage on the GPU: f32 | f16 | bf16
+    stage1_bm25_on_gpu: bool = False         # BM25 postings in HBM, HIP scoring kernels
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
 
@@ -150,7 +151,7 @@ class RetrievalPipeline:
                 top_k_candidates=c.stage1_top_k, batch_size=c.stage1_batch_size,
                 enable_bm25=c.stage1_enable_bm25, bm25_top_k=c.stage1_bm25_top_k,
                 fusion_method=c.stage1_fusion_method, use_fp16=c.stage1_use_fp16,
-                index_dtype=c.stage1_index_dtype))
+                index_dtype=c.stage1_index_dtype, bm25_on_gpu=c.stage1_bm25_on_gpu))
             self.logger.info("Stage 1 initialized")
             self.stage2 = ColBERTScorer(Stage2Config(
                 model_name=c.stage2_model, device=c.device, cache_dir=c.cache_dir,

@@ -54,15 +54,19 @@ class Stage1Config:
     # additive knobs (not in the reference)
     index_dtype: str = "f32"   # storage dtype of the corpus matrix: f32 | f16 | bf16
     gpu_index_device: int = 0
+    bm25_on_gpu: bool = False  # postings in HBM, scored by the HIP BM25 kernels
 
 
 class BM25Index:
     """BM25 (k1=1.2, b=0.75) with the reference's tokenizer and idf
     (reference src/stage1_retriever.py:35-112), over an inverted index."""
 
-    def __init__(self, k1: float = 1.2, b: float = 0.75):
+    def __init__(self, k1: float = 1.2, b: float = 0.75, gpu_device: Optional[int] = None):
         self.k1 = k1
         self.b = b
+        self.gpu_device = gpu_device   # None: score on the host; int: HIP kernels on that GPU
+        self._gpu = None
+        self._term_id: Dict[str, int] = {}
         self.doc_freqs: List[Dict[str, int]] = []
         self.idf: Dict[str, float] = {}
         self.doc_lens: List[int] = []
@@ -106,6 +110,69 @@ class BM25Index:
         lens = np.asarray(self.doc_lens, dtype=np.float64)
         self._len_norm = (self.k1 * (1 - self.b + self.b * lens / self.avg_doc_len)
                           if self.avg_doc_len else np.zeros_like(lens))
+        if self.gpu_device is not None:
+            self._upload()
+
+    # -- GPU mode ------------------------------------------------------------
+    def _upload(self) -> None:
+        """CSR postings + statistics -> HBM (ts_bm25_set_index)."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        if self._gpu is None:
+            self._gpu = ctypes.c_void_p()
+            _lib.check(lib.ts_bm25_create(int(self.gpu_device), ctypes.byref(self._gpu)))
+        terms = sorted(self._postings)
+        self._term_id = {t: i for i, t in enumerate(terms)}
+        off = np.zeros(len(terms) + 1, dtype=np.int64)
+        for i, t in enumerate(terms):
+            off[i + 1] = off[i] + len(self._postings[t][0])
+        nnz = int(off[-1])
+        docs = (np.concatenate([self._postings[t][0] for t in terms]).astype(np.int32)
+                if nnz else np.zeros(1, np.int32))
+        tfs = (np.concatenate([self._postings[t][1] for t in terms]).astype(np.float32)
+               if nnz else np.zeros(1, np.float32))
+        idf = np.array([self.idf[t] for t in terms], dtype=np.float64) if terms else np.zeros(1)
+        ln = np.ascontiguousarray(self._len_norm, dtype=np.float64) if self.corpus_size else np.zeros(1)
+        _lib.check(lib.ts_bm25_set_index(self._gpu, self.corpus_size, len(terms), nnz,
+                                         off.ctypes.data, docs.ctypes.data, tfs.ctypes.data,
+                                         idf.ctypes.data, ln.ctypes.data, float(self.k1 + 1)))
+
+    def _search_gpu(self, query: str, top_k: int) -> List[Tuple[int, float]]:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        ids = np.array([self._term_id[t] for t in self.tokenize(query) if t in self._term_id], dtype=np.int32)
+        k = min(int(top_k), max(self.corpus_size, 1))
+        out_s = np.zeros(max(k, 1), dtype=np.float64)
+        out_i = np.zeros(max(k, 1), dtype=np.int64)
+        n = ctypes.c_int32(0)
+        if k > 0 and len(ids):
+            _lib.check(lib.ts_bm25_search(self._gpu, ids.ctypes.data, len(ids), k, out_s.ctypes.data,
+                                          out_i.ctypes.data, ctypes.byref(n), None))
+        res = [(int(out_i[i]), float(out_s[i])) for i in range(n.value)]
+        if len(res) < min(top_k, self.corpus_size):
+            # every document with a non-zero score is listed; the rest score exactly 0.0 and
+            # follow in ascending id order (the reference's stable sort)
+            seen = {i for i, _ in res}
+            d = 0
+            while len(res) < min(top_k, self.corpus_size):
+                if d not in seen:
+                    res.append((d, 0.0))
+                d += 1
+        return res
+
+    def close(self) -> None:
+        if self._gpu is not None:
+            from . import _lib
+            _lib.load().ts_bm25_destroy(self._gpu)
+            self._gpu = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def score(self, query: str, doc_idx: int) -> float:
         if doc_idx >= len(self.doc_freqs):
@@ -131,6 +198,8 @@ class BM25Index:
         return acc
 
     def search(self, query: str, top_k: int = 10) -> List[Tuple[int, float]]:
+        if self._gpu is not None:
+            return self._search_gpu(query, top_k)
         s = self.scores(query)
         order = np.argsort(-s, kind="stable")[:top_k]  # ties keep ascending doc order
         return [(int(i), float(s[i])) for i in order]
@@ -212,7 +281,8 @@ class Stage1Retriever:
             self.faiss_index.add(embeddings)
         if self.config.enable_bm25:
             if self.bm25_index is None:
-                self.bm25_index = BM25Index()
+                self.bm25_index = BM25Index(
+                    gpu_device=self.config.gpu_index_device if self.config.bm25_on_gpu else None)
             self.bm25_index.fit(self.documents)
         self.logger.info(f"Documents added successfully. Total documents: {len(self.documents)}")
 
@@ -329,7 +399,8 @@ class Stage1Retriever:
                           allow_pickle=False)
             self._create_faiss_index(mat.astype(np.float32))
         if self.config.enable_bm25 and self.documents:
-            self.bm25_index = BM25Index()
+            self.bm25_index = BM25Index(
+                gpu_device=self.config.gpu_index_device if self.config.bm25_on_gpu else None)
             self.bm25_index.fit(self.documents)
         self.logger.info(f"Stage 1 index loaded from {index_path}")
 
