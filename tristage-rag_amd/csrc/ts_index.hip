@@ -447,7 +447,11 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
   prof_mark(h, 2, s);
   // (2) per-query threshold = ~m-th best sample score
-  static const bool dbg_tau_inf = getenv("TS_DEBUG_TAU_INF") != nullptr;  // tuning only
+#ifdef TS_TUNING  // ablation builds only (tools/variants.sh): thresholds = +inf, nothing survives
+  static const bool dbg_tau_inf = getenv("TS_DEBUG_TAU_INF") != nullptr;
+#else
+  constexpr bool dbg_tau_inf = false;
+#endif
   TS_CHECK(ts_launch_tau((const float*)h->sample.p, S, dbg_tau_inf ? 0xFFFFFFFFu : (uint32_t)S, m, nq,
                          h->tau(), s));
   // (3) the full scan; only scores >= tau leave the registers

@@ -44,7 +44,7 @@ __device__ __forceinline__ u32x4 stream_load(const u32x4* p) {
 template <int DT>
 __device__ __forceinline__ void mma_group(f32x16& acc, const u32x4& a,
                                           const u32x4& b) {
-#ifdef DBG_NO_MFMA  // tuning experiments only: keep the operands live, skip the matrix op
+#if defined(TS_TUNING) && defined(DBG_NO_MFMA)  // ablation builds only: keep the operands live, skip the matrix op
   acc[0] += __uint_as_float((a[0] ^ b[0]) & 0x007fffffu);
   acc[1] += __uint_as_float((a[1] ^ b[1]) & 0x007fffffu);
   acc[2] += __uint_as_float((a[2] ^ b[2]) & 0x007fffffu);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
       for (int i = 0; i < TS_RING; ++i) {
 #pragma unroll
         for (int hq = 0; hq < QH; ++hq) {
-#ifdef DBG_NO_LDS
+#if defined(TS_TUNING) && defined(DBG_NO_LDS)  // ablation builds only
           const u32x4 b = ring[(i + 1) % TS_RING];
 #else
           const u32x4 b = ql[(size_t)((g0 + i) * QH + hq) * 64];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     for (int i = 0; i < TS_RING; ++i) {
 #pragma unroll
       for (int hq = 0; hq < QH; ++hq) {
-#ifdef DBG_NO_LDS
+#if defined(TS_TUNING) && defined(DBG_NO_LDS)  // ablation builds only
         const u32x4 b = ring[(i + 1) % TS_RING];
 #else
         const u32x4 b = ql[(size_t)((g0 + i) * QH + hq) * 64];

@@ -254,6 +254,27 @@ class Stage1Retriever:
         norms = np.linalg.norm(embeddings, axis=1, keepdims=True)
         return embeddings / (norms + 1e-8)
 
+    # Device-resident variants: when the encoder runs on the GPU and the index is the HIP
+    # index, embeddings never visit the host — rows are normalised inside ts_index_add
+    # (TS_FLAG_NORMALIZE, the same x/(|x|+1e-8) in fp32) and queries stay tensors.
+    def _device_path(self) -> bool:
+        dev = str(getattr(self.model, "device", "cpu"))
+        return (dev.startswith("cuda") and self._index_factory is None and
+                getattr(self.model, "encode", None) is not None)
+
+    def _encode_batch_tensor(self, texts: List[str]):
+        import torch
+        ctx = (torch.autocast("cuda", dtype=torch.bfloat16) if self.config.use_fp16
+               else torch.autocast("cuda", enabled=False))
+        with ctx:
+            emb = self.model.encode(texts, batch_size=self.config.batch_size, convert_to_numpy=False,
+                                    convert_to_tensor=True, show_progress_bar=False)
+        return emb.float()
+
+    def _normalized_query_tensor(self, texts: List[str]):
+        q = self._encode_batch_tensor(texts)
+        return q / (q.norm(dim=1, keepdim=True) + 1e-8)
+
     # -- index -------------------------------------------------------------
     def _create_faiss_index(self, embeddings: np.ndarray) -> None:
         d = int(embeddings.shape[1])
@@ -274,11 +295,19 @@ class Stage1Retriever:
         if metadata is None:
             metadata = [{}] * len(documents)  # one shared dict, as in the reference (:302)
         self.doc_metadata.extend(metadata)
-        embeddings = self._normalize_embeddings(self._encode_batch(list(documents)))
-        if self.faiss_index is None:
-            self._create_faiss_index(embeddings)
+        if self._device_path():
+            emb = self._encode_batch_tensor(list(documents))
+            if self.faiss_index is None:
+                from .index import FlatIPIndex
+                self.faiss_index = FlatIPIndex(int(emb.shape[1]), dtype=self.config.index_dtype,
+                                               device=self.config.gpu_index_device)
+            self.faiss_index.add(emb, normalize=True)
         else:
-            self.faiss_index.add(embeddings)
+            embeddings = self._normalize_embeddings(self._encode_batch(list(documents)))
+            if self.faiss_index is None:
+                self._create_faiss_index(embeddings)
+            else:
+                self.faiss_index.add(embeddings)
         if self.config.enable_bm25:
             if self.bm25_index is None:
                 self.bm25_index = BM25Index(
@@ -338,8 +367,12 @@ class Stage1Retriever:
         if self.faiss_index is None:
             raise ValueError("No documents indexed. Call add_documents() first.")
         top_k = top_k or self.config.top_k_candidates
-        q = self._normalize_embeddings(self._encode_batch([query]))
-        scores, ids = self.faiss_index.search(q, top_k)
+        if self._device_path():
+            D, I = self.faiss_index.search(self._normalized_query_tensor([query]), top_k)
+            scores, ids = D.cpu().numpy(), I.cpu().numpy()
+        else:
+            q = self._normalize_embeddings(self._encode_batch([query]))
+            scores, ids = self.faiss_index.search(q, top_k)
         dense = [(int(i), float(s)) for i, s in zip(ids[0], scores[0]) if i >= 0]
         results = self._finish(query, dense, top_k)
         self.logger.info(f"Stage 1 search completed. Found {len(results)} candidates")
@@ -353,8 +386,12 @@ class Stage1Retriever:
         top_k = top_k or self.config.top_k_candidates
         if not queries:
             return []
-        q = self._normalize_embeddings(self._encode_batch(list(queries)))
-        scores, ids = self.faiss_index.search(q, top_k)
+        if self._device_path():
+            D, I = self.faiss_index.search(self._normalized_query_tensor(list(queries)), top_k)
+            scores, ids = D.cpu().numpy(), I.cpu().numpy()
+        else:
+            q = self._normalize_embeddings(self._encode_batch(list(queries)))
+            scores, ids = self.faiss_index.search(q, top_k)
         out = []
         for qi, query in enumerate(queries):
             dense = [(int(i), float(s)) for i, s in zip(ids[qi], scores[qi]) if i >= 0]
