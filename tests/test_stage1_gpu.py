@@ -286,3 +286,52 @@ def test_maxsim_indexed_reads_token_store_in_place(torch_mod, dtype):
                          torch.from_numpy(starts[pick]).cuda(), torch.from_numpy(lens[pick].astype(np.int32)).cuda())
     docs = [store[starts[i]: starts[i] + lens[i]] for i in pick]
     np.testing.assert_allclose(got.cpu().numpy(), oracle.maxsim_scores(q, docs), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("k,path", [(2048, "filter"), (3000, "dense")])
+def test_largest_k_on_each_path(k, path):
+    corpus = make_corpus(120_000, 64, seed=31, dtype="f16")
+    queries = make_corpus(3, 64, seed=32, dtype="f16")
+    idx = _index(64, "f16", corpus)
+    D, I = idx.search(queries, k)
+    assert idx.last_search_info()["path"] == path
+    check_topk(D, I, corpus, queries, k)
+    idx.close()
+
+
+def test_empty_query_batch_and_bad_arguments(torch_mod):
+    torch = torch_mod
+    idx = _index(64, "f16", make_corpus(100, 64, dtype="f16"))
+    D, I = idx.search(np.zeros((0, 64), np.float32), 5)
+    assert D.shape == (0, 5) and I.shape == (0, 5)
+    with pytest.raises(ValueError):
+        idx.search(np.zeros((2, 63), np.float32), 5)           # wrong dimension
+    with pytest.raises(ValueError):
+        idx.search(np.zeros((2, 64), np.float32), 0)           # k must be positive
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((2, 65), np.float32))
+    with pytest.raises(ValueError):
+        idx.search(torch.zeros((2, 64)), 5, async_=True)       # async needs device tensors
+    from tristage_rag_amd._lib import TriStageNativeError
+    from tristage_rag_amd.index import FlatIPIndex
+    with pytest.raises(TriStageNativeError, match="needs .* bytes of LDS"):
+        FlatIPIndex(4096, dtype="f16")                          # beyond the LDS-resident query image
+    idx.close()
+
+
+def test_stage1_index_persistence_roundtrip_on_gpu(tmp_path):
+    from tristage_rag_amd.encoders import SentenceEncoder
+    from tristage_rag_amd.stage1_retriever import Stage1Config, Stage1Retriever
+    enc = SentenceEncoder("random:tiny", device="cuda")
+    docs = [f"document number {i} about topic {i % 7}" for i in range(300)]
+    cfg = dict(model_name="random:tiny", device="cuda", cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / "i"),
+               use_fp16=False, index_dtype="f16")
+    a = Stage1Retriever(Stage1Config(**cfg), model=enc)
+    a.add_documents(docs)
+    want = a.search("document about topic 3", top_k=10)
+    a.save_index()
+    b = Stage1Retriever(Stage1Config(**cfg), model=enc)
+    b.load_index()
+    assert b.faiss_index.ntotal == 300 and b.documents == docs
+    got = b.search("document about topic 3", top_k=10)
+    assert [(r["doc_id"], r["score"]) for r in got] == [(r["doc_id"], r["score"]) for r in want]
