@@ -204,6 +204,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
   const int wave = tid >> 6;
   const int kg = p.kg;
 
+  // ---- the first corpus loads go out before anything else, so the HBM round trip
+  // overlaps the Q-image copy below
+  const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
+  int64_t w = (int64_t)blockIdx.x * SCAN_WAVES + wave;
+  const bool active = w < p.nwork;  // (waves without work still join the final flush)
+  const u32x4* base = reinterpret_cast<const u32x4*>(p.corpus) + lane;
+  const size_t blk_units = (size_t)kg * 64;
+  int64_t blk = active ? p.blk0 + w * p.blk_stride : p.blk0;
+  const u32x4* cur = base + (size_t)blk * blk_units;
+  u32x4 ring[TS_RING];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < TS_RING; ++i) ring[i] = stream_load(cur + (size_t)i * 64);
+  }
+
   // ---- prologue: Q image global(L2) -> LDS, once per workgroup
   {
     const u32x4* src = reinterpret_cast<const u32x4*>(p.qimg);
@@ -230,24 +245,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
   }
   __syncthreads();
 
-  const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
-  int64_t w = (int64_t)blockIdx.x * SCAN_WAVES + wave;
-  if (w < p.nwork) {  // (waves without work still join the final flush)
+  if (active) {
 
   float tau[QH];
   if constexpr (MODE == SCAN_FILTER) {
 #pragma unroll
     for (int hq = 0; hq < QH; ++hq) tau[hq] = p.tau[hq * 32 + (lane & 31)];
   }
-
-  const u32x4* base = reinterpret_cast<const u32x4*>(p.corpus) + lane;
-  const size_t blk_units = (size_t)kg * 64;
-  int64_t blk = p.blk0 + w * p.blk_stride;
-  const u32x4* cur = base + (size_t)blk * blk_units;
-
-  u32x4 ring[TS_RING];
-#pragma unroll
-  for (int i = 0; i < TS_RING; ++i) ring[i] = stream_load(cur + (size_t)i * 64);
 
   const u32x4* ql = qlds + lane;
 
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     blk = blkn;
     cur = nxt;
   }
-  }  // w < nwork
+  }  // active
   if constexpr (MODE == SCAN_FILTER) flush_stage(p, st, tid);
 }
 

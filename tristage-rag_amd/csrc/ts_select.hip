@@ -271,10 +271,37 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
   uint32_t pk = 2;
   while (pk < kk) pk <<= 1;
   if (kk >= 1 && pk <= SEL_OUT_CAP && count > 2 * pk) {
-    uint64_t prefix = 0ull;
-    int bits_done = 0;
+    // Scores that survived the filter share their sign, exponent and often the first
+    // mantissa bits: skip the radix passes over the bytes every key has in common.
+    uint64_t all_and = ~0ull, all_or = 0ull;
+    for (uint32_t i = tid; i < count; i += SEL_THREADS) {
+      const uint64_t key = keys[i];
+      all_and &= key;
+      all_or |= key;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      all_and &= shfl_xor_u64(all_and, off);
+      all_or |= shfl_xor_u64(all_or, off);
+    }
+    if (tid == 0) { sh[4] = 0xFFFFFFFFu; sh[5] = 0xFFFFFFFFu; sh[6] = 0u; sh[7] = 0u; }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      atomicAnd(&sh[4], (uint32_t)(all_and >> 32));
+      atomicAnd(&sh[5], (uint32_t)all_and);
+      atomicOr(&sh[6], (uint32_t)(all_or >> 32));
+      atomicOr(&sh[7], (uint32_t)all_or);
+    }
+    __syncthreads();
+    const uint64_t g_and = ((uint64_t)sh[4] << 32) | sh[5], g_or = ((uint64_t)sh[6] << 32) | sh[7];
+    const uint64_t diff = g_and ^ g_or;
+    int skip = diff ? (__builtin_clzll(diff) >> 3) : 7;   // whole bytes all keys agree on
+    if (MODE == SEL_MERGE64 && skip > 3) skip = 3;        // keep the pass that ends the score bits
+    __syncthreads();
+    uint64_t prefix = skip ? (g_or >> (64 - 8 * skip)) : 0ull;
+    int bits_done = 8 * skip;
     uint32_t krem = kk;
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = skip; pass < 8; ++pass) {
       const int shift = 56 - 8 * pass;
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
