@@ -52,6 +52,12 @@ enum ts_metric { TS_METRIC_INNER_PRODUCT = 0 };
 #define TS_FLAG_NO_FILTER 2u    /* search: force the dense (materialise+select) path */
 #define TS_FLAG_ASYNC 8u        /* search: enqueue only (device pointers); results are valid
                                    and verified after ts_index_finish()            */
+#define TS_FLAG_PIPELINE 16u    /* with TS_FLAG_ASYNC: overlap this search's query preparation and
+                                   final selection with the scans of its neighbours (internal
+                                   streams).  The caller guarantees that `queries` is already
+                                   complete in memory when the call is made (not the output of
+                                   work still pending on `stream`); results are ordered after
+                                   the call on `stream` as usual.                             */
 #define TS_FLAG_NORMALIZE 4u    /* add: L2-normalise rows x/(|x|+1e-8) on device first
                                    (reference src/stage1_retriever.py:285-288) */
 
@@ -118,7 +124,9 @@ int ts_index_last_search_info(const ts_index* h, int64_t info[4]);
  * search's own stream (bench.py's roofline leg).  Phases: 0 query prep,
  * 1 sample scan, 2 thresholds, 3 fused scan+filter (the dominant kernel),
  * 4 candidate select, 5 dense path (scan+select), 6-7 unused.  ms[i] is the sum
- * over counts[i] occurrences since the last reset.                           */
+ * over counts[i] occurrences since the last reset.  on = N > 1 times every N-th
+ * search only (a timing event costs a few microseconds in the stream);
+ * asynchronous searches record phase 3 only.                                 */
 int ts_index_set_profiling(ts_index* h, int32_t on);
 int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t reset);
 

@@ -335,3 +335,39 @@ def test_stage1_index_persistence_roundtrip_on_gpu(tmp_path):
     assert b.faiss_index.ntotal == 300 and b.documents == docs
     got = b.search("document about topic 3", top_k=10)
     assert [(r["doc_id"], r["score"]) for r in got] == [(r["doc_id"], r["score"]) for r in want]
+
+
+def test_pipelined_async_searches_match_sync(torch_mod):
+    """TS_FLAG_PIPELINE: many batches in flight on the internal streams, alternating workspace
+    sets, mixed with plain async and synchronous calls — results must equal the synchronous ones."""
+    torch = torch_mod
+    corpus = make_corpus(150_000, 128, dtype="f16")
+    idx = _index(128, "f16", corpus)
+    qs = [torch.from_numpy(make_corpus(64 if i % 3 else 17, 128, seed=200 + i, dtype="f16")).cuda().half()
+          for i in range(12)]
+    torch.cuda.synchronize()
+    want = [idx.search(q, 100) for q in qs]
+    for rounds in range(3):
+        outs = []
+        for i, q in enumerate(qs):
+            if i == 7:
+                outs.append(idx.search(q, 100, async_=True))                 # plain async in between
+            else:
+                outs.append(idx.search(q, 100, async_=True, inputs_ready=True))
+        mid = idx.search(qs[0], 100)                                          # a synchronous call while others are pending
+        assert idx.finish() == []
+        assert torch.equal(mid[1], want[0][1])
+        for (D, I), (D0, I0) in zip(outs, want):
+            assert torch.equal(I, I0) and torch.equal(D, D0)
+    # outputs written into caller buffers that are immediately reused by the caller's stream
+    buf_D = torch.empty((64, 100), dtype=torch.float32, device="cuda")
+    buf_I = torch.empty((64, 100), dtype=torch.int64, device="cuda")
+    acc = []
+    for q in [q for q in qs if q.shape[0] == 64][:4]:
+        idx.search(q, 100, async_=True, inputs_ready=True, out=(buf_D, buf_I))
+        acc.append(buf_I.clone())            # consumer on the caller's stream, ordered after the search
+    idx.finish()
+    exp = [w[1] for q, w in zip(qs, want) if q.shape[0] == 64][:4]
+    for a, b in zip(acc, exp):
+        assert torch.equal(a, b)
+    idx.close()

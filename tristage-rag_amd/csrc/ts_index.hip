@@ -72,6 +72,7 @@ void release(DevBuf& b) {
 
 }  // namespace
 #define TS_NPHASE 8
+#define TS_NSETS 2
 #define TS_ASYNC_SLOTS 256
 #define TS_SLOT_WORDS 80   // 64 counts + status word, padded
 namespace {
@@ -96,8 +97,21 @@ struct ts_index {
   uint4* corpus = nullptr;
   int64_t id_offset = 0;
   int64_t info[4] = {0, 0, 0, 0};
-  // workspace (grown on demand, never inside a steady-state search)
-  DevBuf qimg, small, cand_score, cand_id, sample, dense, list_score, list_id;
+  // Per-search workspace, double-buffered so that consecutive pipelined searches never
+  // share a buffer that is still being read (see search_pass).
+  struct WSet {
+    DevBuf qimg, small, cand_score, cand_id, sample;
+    hipEvent_t ev_pro = nullptr, ev_scan = nullptr, ev_sel = nullptr, ev_in = nullptr;  // timing disabled
+    bool used = false;  // ev_sel has been recorded at least once
+    float* tau() { return (float*)small.p; }
+    uint32_t* cand_cnt() { return (uint32_t*)small.p + 64; }
+    uint32_t* status() { return (uint32_t*)small.p + 128; }
+  };
+  WSet ws[TS_NSETS];
+  uint64_t set_next = 0;
+  hipStream_t s_pro = nullptr, s_scan = nullptr, s_sel = nullptr;  // TS_FLAG_PIPELINE only
+  // workspace shared by the (unpipelined) dense path and the host-pointer staging
+  DevBuf dense, list_score, list_id;
   DevBuf stage, den, qstage, out_s, out_i;
   uint32_t* host_status = nullptr;  // pinned + mapped: written by the select kernel
   uint32_t* host_status_dev = nullptr;  // device view of host_status
@@ -111,20 +125,22 @@ struct ts_index {
   hipEvent_t async_ev[2 * TS_ASYNC_SLOTS] = {};
   // optional per-phase timing with HIP events on the caller's stream
   bool profiling = false;
+  int prof_every = 1;        // time every prof_every-th search (timing events cost ~5 us each in-stream)
+  uint64_t prof_seq = 0;
+  bool prof_now = false;     // this search is being timed
+  bool prof_scan_only = false;  // asynchronous searches: only the scan+filter interval
   hipEvent_t ev[TS_NPHASE + 1] = {};
   int ev_phase[TS_NPHASE + 1] = {};
   int nev = 0;
   double phase_ms[TS_NPHASE] = {};
   int64_t phase_cnt[TS_NPHASE] = {};
-  float* tau() { return (float*)small.p; }
-  uint32_t* cand_cnt() { return (uint32_t*)small.p + 64; }
-  uint32_t* status() { return (uint32_t*)small.p + 128; }
 };
 
 // profiling: mark(h, phase, s) records an event; the time between two marks is
 // charged to the phase of the FIRST mark.  Collected after the search's sync.
 static void prof_mark(ts_index* h, int phase, hipStream_t s) {
-  if (!h->profiling || h->nev > TS_NPHASE) return;
+  if (!h->profiling || !h->prof_now || h->nev > TS_NPHASE) return;
+  if (h->prof_scan_only && phase != 3 && phase != 4) return;
   if (hipEventRecord(h->ev[h->nev], s) != hipSuccess) return;
   h->ev_phase[h->nev] = phase;
   ++h->nev;
@@ -200,8 +216,18 @@ extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metri
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     h->num_cus = prop.multiProcessorCount;
-  int st = ensure(h->small, 4096);
-  if (st == TS_OK) st = ensure(h->qimg, (size_t)L.kg * 2 * 1024);
+  int st = TS_OK;
+  for (ts_index::WSet& w : h->ws) {
+    if (st == TS_OK) st = ensure(w.small, 4096);
+    if (st == TS_OK) st = ensure(w.qimg, (size_t)L.kg * 2 * 1024);
+    if (st == TS_OK && (hipEventCreateWithFlags(&w.ev_pro, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&w.ev_sel, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&w.ev_in, hipEventDisableTiming) != hipSuccess)) {
+      ts_set_error("hipEventCreate failed");
+      st = TS_ERR_HIP;
+    }
+  }
   if (st == TS_OK &&
       (hipHostMalloc((void**)&h->host_status, (size_t)(TS_ASYNC_SLOTS + 1) * TS_SLOT_WORDS * 4, hipHostMallocMapped) != hipSuccess ||
        hipHostGetDevicePointer((void**)&h->host_status_dev, h->host_status, 0) != hipSuccess)) {
@@ -221,10 +247,19 @@ extern "C" int ts_index_destroy(ts_index* h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->corpus) (void)hipFree(h->corpus);
-  DevBuf* bufs[] = {&h->qimg, &h->small, &h->cand_score, &h->cand_id, &h->sample,
-                    &h->dense, &h->list_score, &h->list_id, &h->stage, &h->den,
+  DevBuf* bufs[] = {&h->dense, &h->list_score, &h->list_id, &h->stage, &h->den,
                     &h->qstage, &h->out_s, &h->out_i};
   for (DevBuf* b : bufs) release(*b);
+  for (ts_index::WSet& w : h->ws) {
+    DevBuf* wb[] = {&w.qimg, &w.small, &w.cand_score, &w.cand_id, &w.sample};
+    for (DevBuf* b : wb) release(*b);
+    hipEvent_t evs[] = {w.ev_pro, w.ev_scan, w.ev_sel, w.ev_in};
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
+  }
+  hipStream_t strs[] = {h->s_pro, h->s_scan, h->s_sel};
+  for (hipStream_t st_ : strs)
+    if (st_) (void)hipStreamDestroy(st_);
   if (h->host_status) (void)hipHostFree(h->host_status);
   for (hipEvent_t e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -332,8 +367,8 @@ extern "C" int ts_index_reconstruct(ts_index* h, int64_t row0, int64_t n, float*
 }
 
 // ------------------------------------------------------------------ search
-static int dense_path(ts_index* h, int nq, int qh, int k, float* out_s, int64_t* out_i,
-                      hipStream_t s) {
+static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, float* out_s,
+                      int64_t* out_i, hipStream_t s) {
   const int64_t N = h->ntotal;
   const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
   const int64_t chunk_rows = std::min<int64_t>(kDenseChunkRows, nblk * TS_ROWS_PER_BLOCK);
@@ -348,7 +383,7 @@ static int dense_path(ts_index* h, int nq, int qh, int k, float* out_s, int64_t*
     const int64_t rows = std::min(chunk_rows, N - row0);
     ScanParams sp{};
     sp.corpus = h->corpus;
-    sp.qimg = (const uint4*)h->qimg.p;
+    sp.qimg = (const uint4*)W.qimg.p;
     sp.kg = h->L.kg;
     sp.nq = nq;
     sp.nwork = (rows + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
@@ -394,7 +429,25 @@ static int dense_path(ts_index* h, int nq, int qh, int k, float* out_s, int64_t*
   return TS_OK;
 }
 
-// one pass of <= 32*qh queries (device pointers)
+static int ensure_streams(ts_index* h) {
+  if (h->s_pro) return TS_OK;
+  TS_HIP(hipStreamCreateWithFlags(&h->s_pro, hipStreamNonBlocking));
+  TS_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
+  TS_HIP(hipStreamCreateWithFlags(&h->s_sel, hipStreamNonBlocking));
+  return TS_OK;
+}
+
+// One pass of <= 32*qh queries (device pointers).
+//
+// A pass has three phases, each touching one workspace set W:
+//   P   query prep, sample scan, thresholds      writes W.qimg, W.sample, W.tau; clears W.cand_cnt
+//   S   fused scan+filter over the whole shard   reads W.qimg, W.tau; writes W.cand_*
+//   Sel exact top-k of the candidates            reads W.cand_*; writes the caller's outputs + host slot
+// Normally all three are enqueued on the caller's stream.  With TS_FLAG_PIPELINE they go to
+// three internal streams chained by events (P -> S -> Sel), and the caller's stream only waits
+// for Sel: P of the NEXT search and Sel of the PREVIOUS one then run beside the current S, which
+// leaves an eighth of the CUs free and is HBM-bound anyway.  Passes alternate between two
+// workspace sets; a set is reused only after the Sel that last read it (its ev_sel).
 static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, float* out_s,
                        int64_t* out_i, uint32_t flags, hipStream_t s) {
   const int64_t N = h->ntotal;
@@ -402,16 +455,30 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   const int qh = nq > 32 ? 2 : 1;
   const bool filter = !(flags & TS_FLAG_NO_FILTER) && k <= kMaxFilterK && N >= kMinFilterRows &&
                       N >= 32 * (int64_t)k;
+  const bool async = (flags & TS_FLAG_ASYNC) != 0;
+  const bool pipe = filter && async && (flags & TS_FLAG_PIPELINE) != 0;
+  if (pipe) TS_CHECK(ensure_streams(h));
+  hipStream_t sP = pipe ? h->s_pro : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
+  ts_index::WSet& W = h->ws[h->set_next++ % TS_NSETS];
+  // the set may still be in use by the search that had it last (only possible after pipelined ones)
+  if (W.used) TS_HIP(hipStreamWaitEvent(sP, W.ev_sel, 0));
+  // the output buffers may be memory the caller's stream is still reading (a recycled
+  // allocation): the final phase must not start before the stream's work issued so far
+  if (pipe) TS_HIP(hipEventRecord(W.ev_in, s));
+
   h->nev = 0;
-  prof_mark(h, 0, s);
-  TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)h->qimg.p, h->cand_cnt(),
-                           h->status(), s));
+  h->prof_now = h->profiling && (h->prof_seq++ % (uint64_t)h->prof_every == 0);
+  h->prof_scan_only = async;
+  prof_mark(h, 0, sP);
+  TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), sP));
   if (!filter) {
     h->info[0] = 0; h->info[1] = 0; h->info[2] = 0; h->info[3] = 0;
     prof_mark(h, 5, s);
-    TS_CHECK(dense_path(h, nq, qh, k, out_s, out_i, s));
+    TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
-    if (flags & TS_FLAG_ASYNC) { h->nev = 0; return TS_OK; }  // exact by construction: nothing to verify
+    TS_HIP(hipEventRecord(W.ev_sel, s));
+    W.used = true;
+    if (async) { h->nev = 0; return TS_OK; }  // exact by construction: nothing to verify
     TS_HIP(hipStreamSynchronize(s));
     prof_collect(h);
     return TS_OK;
@@ -427,13 +494,13 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   const int64_t S = nsb * TS_ROWS_PER_BLOCK;
   uint32_t m = (uint32_t)((kOversample * (int64_t)k * S + N - 1) / N);
   m = std::max(m, kMinSampleRank);
-  TS_CHECK(ensure(h->sample, (size_t)nq * S * 4));
-  TS_CHECK(ensure(h->cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
-  TS_CHECK(ensure(h->cand_id, (size_t)TS_MAX_Q * kCandCap * 4));
+  TS_CHECK(ensure(W.sample, (size_t)nq * S * 4));
+  TS_CHECK(ensure(W.cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
+  TS_CHECK(ensure(W.cand_id, (size_t)TS_MAX_Q * kCandCap * 4));
 
   ScanParams sp{};
   sp.corpus = h->corpus;
-  sp.qimg = (const uint4*)h->qimg.p;
+  sp.qimg = (const uint4*)W.qimg.p;
   sp.kg = h->L.kg;
   sp.nq = nq;
   sp.ntotal = N;
@@ -441,38 +508,54 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   sp.nwork = nsb;
   sp.blk0 = 0;
   sp.blk_stride = sstride;
-  sp.dense = (float*)h->sample.p;
+  sp.dense = (float*)W.sample.p;
   sp.dense_ld = S;
-  prof_mark(h, 1, s);
-  TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
-  prof_mark(h, 2, s);
+  prof_mark(h, 1, sP);
+  TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, sP));
+  prof_mark(h, 2, sP);
   // (2) per-query threshold = ~m-th best sample score
 #ifdef TS_TUNING  // ablation builds only (tools/variants.sh): thresholds = +inf, nothing survives
   static const bool dbg_tau_inf = getenv("TS_DEBUG_TAU_INF") != nullptr;
 #else
   constexpr bool dbg_tau_inf = false;
 #endif
-  TS_CHECK(ts_launch_tau((const float*)h->sample.p, S, dbg_tau_inf ? 0xFFFFFFFFu : (uint32_t)S, m, nq,
-                         h->tau(), s));
-  // (3) the full scan; only scores >= tau leave the registers
+  TS_CHECK(ts_launch_tau((const float*)W.sample.p, S, dbg_tau_inf ? 0xFFFFFFFFu : (uint32_t)S, m, nq,
+                         W.tau(), sP));
+  if (pipe) {
+    TS_HIP(hipEventRecord(W.ev_pro, sP));
+    TS_HIP(hipStreamWaitEvent(sS, W.ev_pro, 0));
+  }
+  // (3) the full scan; only scores >= tau leave the registers.  It occupies 7/8 of the CUs:
+  // the kernel is HBM-bound (measured: 224 CUs stream 1.5 % FASTER than 256, tools/cus.sh)
+  // and the free CUs are where the neighbouring searches' small kernels run.
   sp.nwork = nblk;
   sp.blk_stride = 1;
   sp.dense = nullptr;
-  sp.tau = h->tau();
-  sp.cand_cnt = h->cand_cnt();
-  sp.cand_score = (float*)h->cand_score.p;
-  sp.cand_id = (int32_t*)h->cand_id.p;
+  sp.tau = W.tau();
+  sp.cand_cnt = W.cand_cnt();
+  sp.cand_score = (float*)W.cand_score.p;
+  sp.cand_id = (int32_t*)W.cand_id.p;
   sp.cand_cap = kCandCap;
-  prof_mark(h, 3, s);
-  TS_CHECK(ts_launch_scan(h->L, SCAN_FILTER, qh, sp, h->num_cus, s));
-  prof_mark(h, 4, s);
+  int scan_cus = h->num_cus - h->num_cus / 8;
+#ifdef TS_TUNING  // ablation builds only: how many CUs the fused scan may occupy
+  static const int dbg_cus = getenv("TS_SCAN_CUS") ? atoi(getenv("TS_SCAN_CUS")) : 0;
+  if (dbg_cus > 0) scan_cus = dbg_cus;
+#endif
+  prof_mark(h, 3, sS);
+  TS_CHECK(ts_launch_scan(h->L, SCAN_FILTER, qh, sp, scan_cus, sS));
+  prof_mark(h, 4, sS);
+  if (pipe) {
+    TS_HIP(hipEventRecord(W.ev_scan, sS));
+    TS_HIP(hipStreamWaitEvent(sL, W.ev_scan, 0));
+    TS_HIP(hipStreamWaitEvent(sL, W.ev_in, 0));
+  }
   // (4) exact top-k of the candidates; verifies that >= k of them exist
   SelParams p{};
   p.mode = SEL_PAIRS32;
-  p.scores = (const float*)h->cand_score.p;
-  p.ids32 = (const int32_t*)h->cand_id.p;
+  p.scores = (const float*)W.cand_score.p;
+  p.ids32 = (const int32_t*)W.cand_id.p;
   p.stride = kCandCap;
-  p.n_per_q = h->cand_cnt();
+  p.n_per_q = W.cand_cnt();
   p.n_cap = kCandCap;
   p.need = (uint32_t)std::min<int64_t>(k, N);
   p.k = k;
@@ -480,33 +563,35 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   p.out_ids64 = out_i;
   p.out_stride = k;
   p.id_offset = h->id_offset;
-  p.status = h->status();
+  p.status = W.status();
   // the select kernel reports the candidate counts and the status word straight
-  // into mapped host memory: no copy kernel between it and the sync
-  const bool async = (flags & TS_FLAG_ASYNC) != 0;
+  // into mapped host memory: no copy kernel between it and the sync;
   // synchronous searches use the extra last slot, asynchronous ones rotate through the ring
   const int slot = async ? (int)(h->slot_next++ % TS_ASYNC_SLOTS) : TS_ASYNC_SLOTS;
   uint32_t* rep = h->host_status + (size_t)slot * TS_SLOT_WORDS;
   p.host_report = h->host_status_dev + (size_t)slot * TS_SLOT_WORDS;
   for (int i = 0; i < 65; ++i) rep[i] = 0;
-  TS_CHECK(ts_launch_select(p, nq, s));
-  prof_mark(h, -1, s);
+  TS_CHECK(ts_launch_select(p, nq, sL));
+  TS_HIP(hipEventRecord(W.ev_sel, sL));
+  W.used = true;
+  if (pipe) TS_HIP(hipStreamWaitEvent(s, W.ev_sel, 0));  // later work on the caller's stream sees the result
   if (async) {
     // verified later, by ts_index_finish(); nothing here waits for the GPU
     ts_index::Pending& pe = h->pending[h->npending];
     pe.ticket = h->next_ticket; pe.slot = slot; pe.nq = nq; pe.S = (uint32_t)S; pe.m = m;
     pe.e0 = pe.e1 = nullptr;
-    if (h->profiling && h->nev >= 5) {  // keep the scan+filter interval of this pass
-      pe.e0 = h->ev[3]; pe.e1 = h->ev[4];
+    if (h->profiling && h->prof_now && h->nev == 2) {  // the scan+filter interval of this pass
+      pe.e0 = h->ev[0]; pe.e1 = h->ev[1];
       // hand the two events over and give the handle fresh ones
       hipEvent_t n0 = nullptr, n1 = nullptr;
-      if (hipEventCreate(&n0) == hipSuccess && hipEventCreate(&n1) == hipSuccess) { h->ev[3] = n0; h->ev[4] = n1; }
+      if (hipEventCreate(&n0) == hipSuccess && hipEventCreate(&n1) == hipSuccess) { h->ev[0] = n0; h->ev[1] = n1; }
       else { pe.e0 = pe.e1 = nullptr; }
     }
     h->nev = 0;
     ++h->npending;
     return TS_OK;
   }
+  prof_mark(h, -1, s);
   TS_HIP(hipStreamSynchronize(s));
   prof_collect(h);
   uint32_t maxc = 0;
@@ -517,7 +602,7 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
     // list overflowed, e.g. massive score ties): redo this pass exactly.
     h->info[0] = 2;
     prof_mark(h, 5, s);
-    TS_CHECK(dense_path(h, nq, qh, k, out_s, out_i, s));
+    TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
     TS_HIP(hipStreamSynchronize(s));
     prof_collect(h);
@@ -541,6 +626,10 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
   DeviceGuard g(h->device);
   hipStream_t s = (hipStream_t)stream;
   const int qp = (ts_scan_lds_bytes(h->L, 2) <= 160 * 1024) ? 64 : 32;  // queries per pass
+  if ((flags & TS_FLAG_PIPELINE) && !(flags & TS_FLAG_ASYNC)) {
+    ts_set_error("TS_FLAG_PIPELINE needs TS_FLAG_ASYNC");
+    return TS_ERR_INVALID;
+  }
   if (flags & TS_FLAG_ASYNC) {
     if (flags & TS_FLAG_HOST_PTR) { ts_set_error("TS_FLAG_ASYNC needs device pointers"); return TS_ERR_INVALID; }
     const int passes = (nq + qp - 1) / qp;
@@ -622,6 +711,8 @@ extern "C" int ts_index_set_profiling(ts_index* h, int32_t on) {
     for (hipEvent_t& e : h->ev) TS_HIP(hipEventCreate(&e));
   }
   h->profiling = on != 0;
+  h->prof_every = on > 1 ? on : 1;   // on = N: time every N-th search
+  h->prof_seq = 0;
   return TS_OK;
 }
 

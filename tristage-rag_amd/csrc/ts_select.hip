@@ -405,10 +405,11 @@ static int launch_select_t(const SelParams& p, int nq, hipStream_t stream) {
   // LDS: enough 64-bit keys for the entries (or for k when radix-selecting in global)
   uint32_t nmax = p.n_per_q ? p.n_cap : p.n;
   uint32_t need = nmax;
-  if (need > TS_SEL_LDS_KEYS) need = TS_SEL_LDS_KEYS;
+  const uint32_t lds_cap = TS_SEL_LDS_KEYS;
+  if (need > lds_cap) need = lds_cap;
   uint32_t lds_keys = 2;
   while (lds_keys < need) lds_keys <<= 1;
-  if (nmax > TS_SEL_LDS_KEYS) {
+  if (nmax > lds_cap) {
     uint32_t kk = (uint32_t)p.k;
     if (kk > TS_SEL_LDS_KEYS) {
       ts_set_error("k=%d exceeds the supported maximum %d for %u entries", p.k, TS_SEL_LDS_KEYS,

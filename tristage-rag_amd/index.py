@@ -126,7 +126,8 @@ class FlatIPIndex:
                                           None))
         return None
 
-    def search(self, q, k: int, exact_dense: bool = False, async_: bool = False, out=None):
+    def search(self, q, k: int, exact_dense: bool = False, async_: bool = False, out=None,
+               inputs_ready: bool = False):
         """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
         numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out.
 
@@ -134,7 +135,11 @@ class FlatIPIndex:
         stream and the output tensors are returned at once; they are complete and
         verified after :meth:`finish`.  Batches issued this way run back to back on
         the GPU without a host round trip between them.
-        ``out=(D, I)``: CUDA tensors [B,k] float32 / int64 to write into."""
+        ``out=(D, I)``: CUDA tensors [B,k] float32 / int64 to write into.
+        ``inputs_ready=True`` (with ``async_``): the caller guarantees ``q`` is already
+        complete in memory (not the result of work still pending on the stream); the
+        library then pipelines this search's small kernels beside its neighbours' scans
+        (TS_FLAG_PIPELINE)."""
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
@@ -145,6 +150,8 @@ class FlatIPIndex:
             if len(self._pending) >= 60:
                 self.finish()
             flags |= _lib.TS_FLAG_ASYNC
+            if inputs_ready:
+                flags |= _lib.TS_FLAG_PIPELINE
         if _is_tensor(q) and q.is_cuda:
             torch = _torch()
             if q.dim() != 2 or q.shape[1] != self.d:
@@ -218,8 +225,9 @@ class FlatIPIndex:
 
     PHASES = ("qprep", "sample_scan", "tau", "filter_scan", "select", "dense", "_6", "_7")
 
-    def set_profiling(self, on: bool = True) -> None:
-        _lib.check(self._lib.ts_index_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on: bool = True, every: int = 1) -> None:
+        """HIP-event timing of the search phases; ``every=N`` times each N-th search only."""
+        _lib.check(self._lib.ts_index_set_profiling(self._h, (max(int(every), 1) if on else 0)))
 
     def timings(self, reset: bool = True) -> dict:
         """{phase: (total_ms, count)} measured with HIP events on the search stream."""

@@ -83,7 +83,7 @@ class ShardedFlatIPIndex:
             raise ValueError(f"expected {self.n_total} rows, got {rows.shape[0]}")
         self.local_index.add(rows[self.lo:self.hi])
 
-    def search(self, q, k: int, async_: bool = False):
+    def search(self, q, k: int, async_: bool = False, inputs_ready: bool = False):
         """Global top-k for the replicated query batch `q` (tensor).  Returns
         tensors (D float32 [B,k], I int64 [B,k]) identical on every rank.
 
@@ -100,7 +100,7 @@ class ShardedFlatIPIndex:
         I = packed[4 * B * k:].view(torch.int64).view(B, k)
         if self.hi > self.lo:
             if getattr(self.local_index, "supports_out", False):
-                self.local_index.search(q, k, async_=async_, out=(D, I))
+                self.local_index.search(q, k, async_=async_, out=(D, I), inputs_ready=inputs_ready and async_)
             else:
                 d, i = self.local_index.search(q, k)
                 D.copy_(torch.as_tensor(d))
