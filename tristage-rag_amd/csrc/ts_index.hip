@@ -431,9 +431,15 @@ static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, flo
 
 static int ensure_streams(ts_index* h) {
   if (h->s_pro) return TS_OK;
-  TS_HIP(hipStreamCreateWithFlags(&h->s_pro, hipStreamNonBlocking));
-  TS_HIP(hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking));
-  TS_HIP(hipStreamCreateWithFlags(&h->s_sel, hipStreamNonBlocking));
+  // The scan stream outranks the two helper streams: when a scan and the previous
+  // search's select become runnable at the same instant (both wait for the same scan
+  // to end), the scan's workgroups must be placed first — a scan workgroup that starts
+  // late finishes late, because every workgroup owns a fixed share of the rows.
+  int lo = 0, hi = 0;  // numerically lower = higher priority
+  TS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  TS_HIP(hipStreamCreateWithPriority(&h->s_scan, hipStreamNonBlocking, hi));
+  TS_HIP(hipStreamCreateWithPriority(&h->s_pro, hipStreamNonBlocking, lo));
+  TS_HIP(hipStreamCreateWithPriority(&h->s_sel, hipStreamNonBlocking, lo));
   return TS_OK;
 }
 
