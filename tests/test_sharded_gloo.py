@@ -71,3 +71,64 @@ def test_sharded_search_equals_unsharded(tmp_path, world, n, k):
     for r in range(world):                                    # identical on every rank, equal to unsharded
         assert np.array_equal(np.load(tmp_path / f"I{r}.npy"), I0)
         np.testing.assert_array_equal(np.load(tmp_path / f"D{r}.npy"), D0)
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from doubles import OracleIndex, oracle_maxsim, oracle_merge
+    from tristage_rag_amd.encoders import SentenceEncoder
+    from tristage_rag_amd.parallel_pipeline import ShardedRetrievalPipeline
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    from tristage_rag_amd.stage1_retriever import Stage1Config, Stage1Retriever
+    from tristage_rag_amd.stage2_rescorer import ColBERTScorer, Stage2Config
+    from tristage_rag_amd.stage3_reranker import AdaptiveCrossEncoderReranker, Stage3Config
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)
+        words = "alpha beta gamma delta neural network retrieval index query vector gpu memory token".split()
+        docs = [" ".join(rng.choice(words, size=int(rng.integers(3, 14)))) + f" d{i}" for i in range(57)]
+
+        def build(cls, **kw):
+            pc = PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                                device="cpu", cache_dir=os.path.join(out_dir, "m"), index_dir=os.path.join(out_dir, "i"),
+                                log_file=os.path.join(out_dir, f"r{rank}.log"), log_level="ERROR", stage1_top_k=20,
+                                stage2_top_k=9, stage3_top_k=4, save_intermediate_results=True)
+            p = cls(config=pc, **kw)
+            p.stage1 = Stage1Retriever(Stage1Config(model_name="random:tiny", device="cpu", cache_dir=pc.cache_dir,
+                                                    index_dir=pc.index_dir, top_k_candidates=20),
+                                       model=SentenceEncoder("random:tiny", device="cpu"),
+                                       index_factory=lambda d: OracleIndex(d))
+            p.stage2 = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=9),
+                                     maxsim_fn=oracle_maxsim)
+            p.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(model_name="random:tiny", device="cpu", top_k_final=4))
+            return p
+
+        par = build(ShardedRetrievalPipeline)
+        par._merge_fn = oracle_merge
+        par.add_documents(docs)
+        assert par.stage1.faiss_index.local_index.ntotal == shard_bounds(57, world, rank)[1] - shard_bounds(57, world, rank)[0]
+        single = build(RetrievalPipeline)
+        single.add_documents(docs)
+        res = []
+        for q in ("neural network retrieval", "gpu memory d7", "zeta"):
+            a, b = par.search(q), single.search(q)
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (q, stage)
+                np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+            res.append([r["doc_id"] for r in a["results"]])
+        json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pipeline_equals_single_process_pipeline(tmp_path):
+    """All three stages over 2 ranks (row-sharded stage 1 incl. BM25+RRF, data-parallel stages
+    2 and 3) == the single-process pipeline, and identical on every rank."""
+    import json
+    mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert json.load(open(tmp_path / "res0.json")) == json.load(open(tmp_path / "res1.json"))

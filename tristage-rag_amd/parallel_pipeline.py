@@ -1,0 +1,125 @@
+"""Three-stage pipeline over R GPUs of one node (one process per GPU, RCCL).
+
+SURVEY.md §8e.  The reference has no multi-device code (its batch_search is a
+sequential loop, src/retrieval_pipeline.py:444-448); this is the scale-out of the
+same ``RetrievalPipeline.search``:
+
+  stage 1  the corpus matrix is row-sharded: rank r encodes and indexes only rows
+           shard_bounds(N, R, r) (index build is data parallel too); a query is
+           searched on every shard, partial top-k lists are all-gathered and merged
+           (tristage_rag_amd.sharded).  BM25 statistics need the whole corpus and
+           are replicated.
+  stage 2  replicas: every rank holds the encoder; rank r scores candidates r, r+R, …
+           and the float32 scores are all-gathered.
+  stage 3  same for the cross-encoder pairs; min-max normalisation and sorting happen
+           after the gather, so every rank returns the identical result — the
+           single-GPU one up to batch-padding noise.
+
+Documents are passed identically to every rank, in ONE ``add_documents`` call.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .retrieval_pipeline import PipelineConfig, RetrievalPipeline
+from .sharded import ShardedFlatIPIndex, shard_bounds
+from .stage1_retriever import BM25Index
+
+
+def _world(group):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return dist, 1, 0
+    return dist, dist.get_world_size(group), dist.get_rank(group)
+
+
+def gather_interleaved(local_scores: List[float], n_total: int, group=None, device="cpu") -> List[float]:
+    """Rank r computed the scores of items r, r+R, r+2R, …; returns all n_total scores in
+    item order on every rank (one all-gather of float32)."""
+    dist, R, rank = _world(group)
+    if R == 1:
+        return list(local_scores)
+    per = -(-n_total // R)
+    buf = torch.full((per,), float("nan"), dtype=torch.float32, device=device)
+    if local_scores:
+        buf[: len(local_scores)] = torch.tensor(local_scores, dtype=torch.float32, device=device)
+    out = torch.empty((R * per,), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    table = out.view(R, per).cpu().numpy()
+    return [float(table[i % R, i // R]) for i in range(n_total)]
+
+
+class ShardedRetrievalPipeline(RetrievalPipeline):
+    def __init__(self, config_path: Optional[str] = None, config: Optional[PipelineConfig] = None,
+                 group=None):
+        super().__init__(config_path=config_path, config=config)
+        self.group = group
+        self._dist, self.world_size, self.rank = _world(group)
+        self._indexed = False
+
+    def _comm_device(self):
+        backend = self._dist.get_backend(self.group) if self.world_size > 1 else "gloo"
+        return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    # -- indexing: each rank encodes and stores only its row shard ---------------
+    def add_documents(self, documents: List[str], metadata: Optional[List[Dict[str, Any]]] = None):
+        if self._indexed:
+            raise ValueError("ShardedRetrievalPipeline takes the corpus in one add_documents call")
+        if not self.stage1:
+            self.initialize_stages()
+        s1 = self.stage1
+        n = len(documents)
+        lo, hi = shard_bounds(n, self.world_size, self.rank)
+        s1.documents.extend(documents)
+        s1.doc_metadata.extend(metadata if metadata is not None else [{}] * n)
+        mine = list(documents[lo:hi])
+        if s1._device_path():
+            emb = s1._encode_batch_tensor(mine) if mine else None
+            d = int(emb.shape[1]) if emb is not None else int(s1.embedding_dim)
+            local = None
+            normalize = True
+        else:
+            emb = s1._normalize_embeddings(s1._encode_batch(mine)) if mine else None
+            d = int(emb.shape[1]) if emb is not None else int(s1.embedding_dim)
+            local = s1._index_factory(d) if s1._index_factory is not None else None
+            normalize = False
+        index = ShardedFlatIPIndex(d, n, dtype=s1.config.index_dtype, device=s1.config.gpu_index_device,
+                                   group=self.group, local_index=local,
+                                   merge_fn=getattr(self, "_merge_fn", None))
+        if emb is not None:
+            if normalize:
+                index.local_index.add(emb, normalize=True)
+            else:
+                index.local_index.add(emb)
+        s1.faiss_index = index
+        if s1.config.enable_bm25:
+            s1.bm25_index = BM25Index(gpu_device=s1.config.gpu_index_device if s1.config.bm25_on_gpu else None)
+            s1.bm25_index.fit(s1.documents)
+        if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
+            self.stage2.index_documents(list(documents), 0)   # replicas keep the whole token store
+        self._install_data_parallel_scoring()
+        self._indexed = True
+
+    # -- stages 2 and 3: replicas, work split by candidate ------------------------
+    def _install_data_parallel_scoring(self) -> None:
+        if self.world_size == 1:
+            return
+        R, rank, group, dev = self.world_size, self.rank, self.group, self._comm_device()
+        s2, s3 = self.stage2, self.stage3
+        base2, base3 = s2.score_candidates, s3.raw_scores
+
+        def score_candidates(query, candidates):
+            mine = candidates[rank::R]
+            local = base2(query, mine) if mine else []
+            return gather_interleaved(local, len(candidates), group, dev)
+
+        def raw_scores(query, documents):
+            mine = documents[rank::R]
+            local = [float(x) for x in base3(query, mine)] if mine else []
+            return gather_interleaved(local, len(documents), group, dev)
+
+        s2.score_candidates = score_candidates
+        s3.raw_scores = raw_scores

@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import numpy as np
+
 
 def shard_bounds(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Rows [lo, hi) held by `rank`; contiguous, ceil-divided."""
@@ -90,6 +92,9 @@ class ShardedFlatIPIndex:
         ``async_=True``: local search, all-gather and merge are only enqueued (all
         three are stream-ordered); call :meth:`finish` before reading the result."""
         import torch
+        if not torch.is_tensor(q):  # FAISS-style numpy call: same path on host tensors, numpy back
+            D, I = self.search(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)), k)
+            return D.cpu().numpy(), I.cpu().numpy()
         if async_ and len(self._pending) >= 48:
             self.finish()
         B = q.shape[0]

@@ -251,16 +251,21 @@ class ColBERTScorer:
         scores = fn(q, self.token_store.data, starts_all[sel], lens_all[sel], self.config.scoring_method)
         return [float(x) for x in scores.detach().cpu().tolist()]
 
-    def rescore_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
-        if not candidates:
-            return []
-        self.logger.info(f"Rescoring {len(candidates)} candidates with Stage 2")
+    def score_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[float]:
+        """stage-2 score of every candidate, in order (one kernel launch, one host copy)."""
         query_embeddings = self.encode_query(query)
         scores = self._score_from_store(query_embeddings, candidates)
         if scores is None:
             documents = [c["document"] for c in candidates]
             doc_embeddings_list = self.encode_documents_batch(documents)
             scores = self.score_all(query_embeddings, doc_embeddings_list)
+        return scores
+
+    def rescore_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
+        if not candidates:
+            return []
+        self.logger.info(f"Rescoring {len(candidates)} candidates with Stage 2")
+        scores = self.score_candidates(query, candidates)
         scored = []
         for cand, s in zip(candidates, scores):
             u = cand.copy()

@@ -94,13 +94,17 @@ class CrossEncoderReranker:
                 all_scores.extend(scores.cpu().tolist())
         return all_scores
 
+    def raw_scores(self, query: str, documents: List[str]) -> List[float]:
+        """Activated model scores of (query, doc) pairs, before the min-max step."""
+        pairs = self._prepare_input_pairs(query, documents)
+        return (self._predict_with_sentence_transformers(pairs) if self.use_sentence_transformers
+                else self._predict_with_huggingface(pairs))
+
     def predict(self, query: str, documents: List[str]) -> List[float]:
         """reference :192-210"""
         if not documents:
             return []
-        pairs = self._prepare_input_pairs(query, documents)
-        scores = (self._predict_with_sentence_transformers(pairs) if self.use_sentence_transformers
-                  else self._predict_with_huggingface(pairs))
+        scores = self.raw_scores(query, documents)
         if self.config.normalize_scores:
             scores = self._normalize_scores(scores)
         return scores
