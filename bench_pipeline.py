@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--cache", action="store_true", help="cache stage-2 token matrices per document")
     ap.add_argument("--store", action="store_true",
                     help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
+    ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -42,7 +43,7 @@ def main():
                         stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=False,
                         stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
                         stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
-                        stage2_precompute_document_embeddings=args.store)
+                        stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs)
     p = RetrievalPipeline(config=pc)
     t0 = time.perf_counter()
     p.add_documents(docs)
@@ -58,14 +59,19 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = {k: float(np.mean([o["timing"][k] for o in outs])) for k in ("stage1_time", "stage2_time", "stage3_time", "total_time")}
+    g1 = getattr(p.stage1.model, "_graphed", None)
+    g2 = getattr(p.stage2, "_graphed", None)
+    graph_state = {"stage1": None if g1 is None else {"buckets": sorted(g1._graphs), "eager_fallback": g1._broken},
+                   "stage2": None if g2 is None else {"buckets": sorted(g2._graphs), "eager_fallback": g2._broken}}
     print(json.dumps({
         "metric": "full 3-stage pipeline queries/sec (random-init models, throughput only)",
         "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
-                   "stage2_token_cache": args.cache, "stage2_token_store": args.store},
+                   "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
+        "hip_graph_state": graph_state,
         "data": "synthetic"}))
 
 

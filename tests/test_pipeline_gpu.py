@@ -118,3 +118,36 @@ def test_token_store_pipeline_equals_reencoding_pipeline(tmp_path):
         assert set(sa) == set(sb) or len(set(sa) ^ set(sb)) <= 2
         for k in set(sa) & set(sb):
             assert abs(sa[k] - sb[k]) < 1e-3
+
+
+def test_hip_graph_query_forwards_match_eager(tmp_path):
+    """Batch-1 encoder forwards replayed from captured HIP graphs (padded to a length bucket)
+    give the eager results: stage-1 embeddings, stage-2 token matrices, final ranking."""
+    import torch
+    from tristage_rag_amd.encoders import SentenceEncoder
+    from tristage_rag_amd.stage2_rescorer import ColBERTScorer, Stage2Config
+    eager = SentenceEncoder("random:tiny", device="cuda")
+    graph = SentenceEncoder("random:tiny", device="cuda", use_hip_graph=True)
+    texts = ["a", "neural network attention", " ".join(["word"] * 7), " ".join(["tok"] * 30), " ".join(["z"] * 200)]
+    for t in texts * 2:                                   # second round replays the captured graphs
+        np.testing.assert_allclose(graph.encode(t), eager.encode(t), atol=1e-4)
+    assert graph._graphed is not None and not graph._graphed._broken and len(graph._graphed._graphs) >= 3
+    s_e = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cuda", use_fp16=False))
+    s_g = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cuda", use_fp16=False, use_hip_graph=True))
+    for t in texts:
+        a, b = s_e.encode_query(t), s_g.encode_query(t)
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, atol=1e-4)
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    docs = _corpus(200)
+    outs = []
+    for graphs in (False, True):
+        pc = PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                            device="cuda", cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / "i"),
+                            log_file=str(tmp_path / f"g{graphs}.log"), stage1_top_k=30, stage2_top_k=10,
+                            stage3_top_k=5, stage1_enable_bm25=False, stage1_use_fp16=False,
+                            stage2_use_fp16=False, stage3_use_fp16=False, use_hip_graphs=graphs)
+        p = RetrievalPipeline(config=pc)
+        p.add_documents(docs)
+        outs.append([[r["doc_id"] for r in p.search(q)["results"]] for q in ("neural network", "gpu memory index")])
+    assert outs[0] == outs[1]

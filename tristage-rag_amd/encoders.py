@@ -190,14 +190,85 @@ def _autocast(device: str, enabled: bool, dtype=torch.bfloat16):
     return contextlib.nullcontext()
 
 
+# --------------------------------------------------------------------------- hipGraph replay
+class GraphedForward:
+    """Batch-1 encoder forwards replayed from captured HIP graphs.
+
+    A single query through a 12-22 layer encoder is ~200 tiny kernels: launch-bound
+    (4.6 ms eager vs 2.5 ms replayed for BERT-base, 8.1 vs 5.0 ms for ModernBERT-base on
+    MI355X, outputs bit-identical in tools/graph_probe.py).  The token sequence is padded
+    to the next length bucket (pad id + attention-mask 0, so valid positions are
+    unchanged), one graph per bucket is captured on first use and replayed afterwards.
+    If a model cannot be captured the eager GPU forward is used (and remembered)."""
+
+    BUCKETS = (8, 16, 32, 64, 128, 192, 256, 384, 512)
+
+    def __init__(self, model, pad_token_id: int = 0, amp_dtype=None):
+        self.model = model
+        self.pad = int(pad_token_id or 0)
+        self.amp_dtype = amp_dtype
+        self._graphs: Dict[int, Tuple[Any, torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._broken = False
+
+    def _run(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        # Autocast keeps low-precision copies of the weights in a cache that is freed when
+        # the OUTERMOST autocast context exits.  A graph captured while such a copy is
+        # cached would keep reading that freed memory on every replay, so the forward runs
+        # outside any caller context and with the cache off (the casts become graph nodes).
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            if self.amp_dtype is not None:
+                with torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False):
+                    return self.model(input_ids=ids, attention_mask=mask).last_hidden_state
+            return self.model(input_ids=ids, attention_mask=mask).last_hidden_state
+
+    def _capture(self, L: int, device):
+        ids = torch.full((1, L), self.pad, dtype=torch.long, device=device)
+        mask = torch.zeros((1, L), dtype=torch.long, device=device)
+        mask[:, 0] = 1
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._run(ids, mask)
+        torch.cuda.current_stream(device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run(ids, mask)
+        return g, ids, mask, out
+
+    def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """input_ids / attention_mask [1, n] on the GPU -> last_hidden_state [1, n, H] (a copy)."""
+        n = int(input_ids.shape[1])
+        bucket = next((b for b in self.BUCKETS if b >= n), None)
+        if self._broken or bucket is None or input_ids.shape[0] != 1:
+            return self._run(input_ids, attention_mask)
+        if bucket not in self._graphs:
+            try:
+                self._graphs[bucket] = self._capture(bucket, input_ids.device)
+            except Exception:
+                self._broken = True
+                torch.cuda.synchronize()
+                return self._run(input_ids, attention_mask)
+        g, ids, mask, out = self._graphs[bucket]
+        ids.fill_(self.pad)
+        mask.zero_()
+        ids[:, :n].copy_(input_ids)
+        mask[:, :n].copy_(attention_mask)
+        g.replay()
+        return out[:, :n].clone()
+
+
 # --------------------------------------------------------------------------- bi-encoder
 class SentenceEncoder:
     """Stand-in for sentence_transformers.SentenceTransformer (see module docstring)."""
 
     def __init__(self, model_name: str, device: str = "auto", cache_folder: str = "./models",
-                 max_seq_length: Optional[int] = None, amp_dtype=torch.bfloat16, seed: int = 0):
+                 max_seq_length: Optional[int] = None, amp_dtype=torch.bfloat16, seed: int = 0,
+                 use_hip_graph: bool = False):
         self.model_name = model_name
         self.device = resolve_device(device)
+        self.use_hip_graph = use_hip_graph
+        self._graphed: Optional[GraphedForward] = None
         self.tokenizer, self.model, src = load_backbone(model_name, cache_folder, "base", seed=seed)
         self.model.to(self.device).eval()
         self.amp_dtype = amp_dtype
@@ -271,7 +342,14 @@ class SentenceEncoder:
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
                 enc.pop("token_type_ids")
-            hidden = self.model(**enc).last_hidden_state
+            if self.use_hip_graph and len(idx) == 1 and str(self.device).startswith("cuda"):
+                if self._graphed is None:  # the autocast state of the first call is baked into the graphs
+                    self._graphed = GraphedForward(
+                        self.model, getattr(self.tokenizer, "pad_token_id", 0),
+                        torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
+                hidden = self._graphed(enc["input_ids"], enc["attention_mask"])
+            else:
+                hidden = self.model(**enc).last_hidden_state
             emb = self._pool(hidden.float(), enc["attention_mask"])
             for d in self.dense:
                 emb = d(emb)

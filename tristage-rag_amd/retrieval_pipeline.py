@@ -68,6 +68,7 @@ class PipelineConfig:
     stage1_bm25_on_gpu: bool = False         # BM25 postings in HBM, HIP scoring kernels
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
+    use_hip_graphs: bool = False             # batch-1 query forwards of stages 1/2 replayed from HIP graphs
 
 
 # (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
@@ -151,7 +152,8 @@ class RetrievalPipeline:
                 top_k_candidates=c.stage1_top_k, batch_size=c.stage1_batch_size,
                 enable_bm25=c.stage1_enable_bm25, bm25_top_k=c.stage1_bm25_top_k,
                 fusion_method=c.stage1_fusion_method, use_fp16=c.stage1_use_fp16,
-                index_dtype=c.stage1_index_dtype, bm25_on_gpu=c.stage1_bm25_on_gpu))
+                index_dtype=c.stage1_index_dtype, bm25_on_gpu=c.stage1_bm25_on_gpu,
+                use_hip_graph=c.use_hip_graphs))
             self.logger.info("Stage 1 initialized")
             self.stage2 = ColBERTScorer(Stage2Config(
                 model_name=c.stage2_model, device=c.device, cache_dir=c.cache_dir,
@@ -159,7 +161,8 @@ class RetrievalPipeline:
                 top_k_candidates=c.stage2_top_k, use_fp16=c.stage2_use_fp16,
                 scoring_method=c.stage2_scoring_method,
                 cache_document_embeddings=c.stage2_cache_document_embeddings,
-                precompute_document_embeddings=c.stage2_precompute_document_embeddings))
+                precompute_document_embeddings=c.stage2_precompute_document_embeddings,
+                use_hip_graph=c.use_hip_graphs))
             self.logger.info("Stage 2 initialized")
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,

@@ -55,6 +55,7 @@ class Stage1Config:
     index_dtype: str = "f32"   # storage dtype of the corpus matrix: f32 | f16 | bf16
     gpu_index_device: int = 0
     bm25_on_gpu: bool = False  # postings in HBM, scored by the HIP BM25 kernels
+    use_hip_graph: bool = False  # replay single-query encoder forwards from HIP graphs
 
 
 class BM25Index:
@@ -229,7 +230,8 @@ class Stage1Retriever:
             from .encoders import SentenceEncoder
             self.logger.info(f"Loading Stage 1 model: {self.config.model_name}")
             self.model = SentenceEncoder(self.config.model_name, device=self.config.device,
-                                         cache_folder=self.config.cache_dir)
+                                         cache_folder=self.config.cache_dir,
+                                         use_hip_graph=self.config.use_hip_graph)
         if hasattr(self.model, "get_sentence_embedding_dimension"):
             self.embedding_dim = self.model.get_sentence_embedding_dimension()
         else:

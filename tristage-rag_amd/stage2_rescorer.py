@@ -40,6 +40,7 @@ class Stage2Config:
     # additive
     cache_document_embeddings: bool = False      # memoise token matrices per document text
     precompute_document_embeddings: bool = False  # resident token store filled at add time
+    use_hip_graph: bool = False                   # replay the batch-1 query forward from a HIP graph
 
 
 class TokenStore:
@@ -101,6 +102,7 @@ class ColBERTScorer:
         self._doc_cache: Dict[str, torch.Tensor] = {}
         self.token_store = TokenStore()        # filled by index_documents()
         self._store_slot: Dict[int, int] = {}  # pipeline doc_id -> slot in the store
+        self._graphed = None
         self._load_model()
 
     def _get_device(self) -> str:
@@ -159,6 +161,12 @@ class ColBERTScorer:
         enc = self.tokenizer(text, truncation=True, max_length=self.config.max_seq_length,
                              return_tensors="pt", padding=False)
         enc = self._model_inputs(enc)
+        if self.config.use_hip_graph and str(self.device).startswith("cuda"):
+            if self._graphed is None:
+                from .encoders import GraphedForward
+                self._graphed = GraphedForward(self.model, getattr(self.tokenizer, "pad_token_id", 0),
+                                               torch.bfloat16 if self.use_amp else None)
+            return self._graphed(enc["input_ids"], enc["attention_mask"])  # unpadded input: all tokens valid
         hidden = self._forward(enc)
         n = int(enc["attention_mask"].sum().item())
         return hidden[:, :n, :]
