@@ -96,7 +96,7 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
                 index.local_index.add(emb)
         s1.faiss_index = index
         if s1.config.enable_bm25:
-            s1.bm25_index = BM25Index(gpu_device=s1.config.gpu_index_device if s1.config.bm25_on_gpu else None)
+            s1.bm25_index = BM25Index(gpu_device=s1._bm25_device())
             s1.bm25_index.fit(s1.documents)
         if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
             self.stage2.index_documents(list(documents), 0)   # replicas keep the whole token store

@@ -65,7 +65,7 @@ class PipelineConfig:
     max_memory_usage_gb: float = 4.0
     # ---- additive (MI355X) ----
     stage1_index_dtype: str = "f32"          # corpus storage on the GPU: f32 | f16 | bf16
-    stage1_bm25_on_gpu: bool = False         # BM25 postings in HBM, HIP scoring kernels
+    stage1_bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM, HIP scoring; None = when a GPU is used
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # batch-1 query forwards of stages 1/2 replayed from HIP graphs

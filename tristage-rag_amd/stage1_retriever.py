@@ -54,7 +54,8 @@ class Stage1Config:
     # additive knobs (not in the reference)
     index_dtype: str = "f32"   # storage dtype of the corpus matrix: f32 | f16 | bf16
     gpu_index_device: int = 0
-    bm25_on_gpu: bool = False  # postings in HBM, scored by the HIP BM25 kernels
+    bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM + HIP scoring kernels; None = whenever
+                                        # the HIP index is in use (a GPU is present)
     use_hip_graph: bool = False  # replay single-query encoder forwards from HIP graphs
 
 
@@ -259,6 +260,13 @@ class Stage1Retriever:
     # Device-resident variants: when the encoder runs on the GPU and the index is the HIP
     # index, embeddings never visit the host — rows are normalised inside ts_index_add
     # (TS_FLAG_NORMALIZE, the same x/(|x|+1e-8) in fp32) and queries stay tensors.
+    def _bm25_device(self) -> Optional[int]:
+        on = self.config.bm25_on_gpu
+        if on is None:
+            import torch
+            on = self._index_factory is None and torch.cuda.is_available()
+        return self.config.gpu_index_device if on else None
+
     def _device_path(self) -> bool:
         dev = str(getattr(self.model, "device", "cpu"))
         return (dev.startswith("cuda") and self._index_factory is None and
@@ -312,8 +320,7 @@ class Stage1Retriever:
                 self.faiss_index.add(embeddings)
         if self.config.enable_bm25:
             if self.bm25_index is None:
-                self.bm25_index = BM25Index(
-                    gpu_device=self.config.gpu_index_device if self.config.bm25_on_gpu else None)
+                self.bm25_index = BM25Index(gpu_device=self._bm25_device())
             self.bm25_index.fit(self.documents)
         self.logger.info(f"Documents added successfully. Total documents: {len(self.documents)}")
 
@@ -438,8 +445,7 @@ class Stage1Retriever:
                           allow_pickle=False)
             self._create_faiss_index(mat.astype(np.float32))
         if self.config.enable_bm25 and self.documents:
-            self.bm25_index = BM25Index(
-                gpu_device=self.config.gpu_index_device if self.config.bm25_on_gpu else None)
+            self.bm25_index = BM25Index(gpu_device=self._bm25_device())
             self.bm25_index.fit(self.documents)
         self.logger.info(f"Stage 1 index loaded from {index_path}")
 
