@@ -66,5 +66,14 @@ def test_sharded_index_rccl_world_of_one():
         idx.finish()
         for Da, Ia in outs:
             assert torch.equal(Ia, I) and torch.equal(Da, D)
+        # pipelined submission (internal streams) interleaved with the RCCL exchange + merge,
+        # exactly what bench.py does for N > 1
+        q2 = torch.from_numpy(make_corpus(64, d, seed=10, dtype="f16")).cuda().half()
+        D2, I2 = idx.search(q2, k)
+        torch.cuda.synchronize()
+        outs = [idx.search(q if i % 2 == 0 else q2, k, async_=True, inputs_ready=True) for i in range(60)]
+        idx.finish()
+        for i, (Da, Ia) in enumerate(outs):
+            assert torch.equal(Ia, I if i % 2 == 0 else I2) and torch.equal(Da, D if i % 2 == 0 else D2), i
     finally:
         dist.destroy_process_group()
