@@ -54,6 +54,8 @@ def parse_args():
                          "1.25 M rows per rank), off for N=1 (no gain at 10 M rows and the overlapped scan "
                          "runs 2-3 %% slower)")
     ap.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the scan kernel")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: with one rank, still run the RCCL all-gather + merge every step")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     return ap.parse_args()
 
@@ -116,6 +118,10 @@ def main():
     else:
         torch.cuda.set_device(0)
         local_rank = 0
+        if args.force_exchange:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     if args.gpus != world:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -133,15 +139,16 @@ def main():
     for r0 in range(lo, hi, blk):
         n = min(blk, hi - r0)
         local.add(gen_rows(torch, n, args.dim, 1234 + r0 // blk, tdt, device))
-    if world > 1:
+    if world > 1 or args.force_exchange:
         index = ShardedFlatIPIndex(args.dim, args.rows, dtype=args.dtype, device=local_rank,
                                    local_index=local)
+        index.always_exchange = args.force_exchange
     else:
         index = local
     queries = [gen_rows(torch, args.batch, args.dim, 4321 + i, tdt, device) for i in range(4)]
     torch.cuda.synchronize()
 
-    pipeline = (args.pipeline == "on") or (args.pipeline == "auto" and world > 1)
+    pipeline = (args.pipeline == "on") or (args.pipeline == "auto" and (world > 1 or args.force_exchange))
 
     def step(i):
         if args.sync:
@@ -242,6 +249,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
