@@ -71,6 +71,7 @@ class FlatIPIndex:
                                              ctypes.byref(self._h)))
         self.is_trained = True  # FAISS attribute; a flat index needs no training
         self._pending = {}      # ticket -> (q, k, D, I) of unfinished async searches
+        self._pending_passes = 0
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -147,7 +148,8 @@ class FlatIPIndex:
         if async_:
             if not (_is_tensor(q) and q.is_cuda):
                 raise ValueError("async_ search needs a CUDA tensor")
-            if len(self._pending) >= 60:
+            # the library tracks at most 64 unfinished passes (one per <= 64 queries)
+            if self._pending_passes + (q.shape[0] + 31) // 32 > 60:
                 self.finish()
             flags |= _lib.TS_FLAG_ASYNC
             if inputs_ready:
@@ -170,6 +172,7 @@ class FlatIPIndex:
                              flags, _stream_ptr(self.device))
             if async_:
                 self._pending[int(self._lib.ts_index_last_ticket(self._h))] = (q, k, D, I)
+                self._pending_passes += (B + 31) // 32
             return D, I
         if _is_tensor(q):
             q = q.detach().float().numpy()
@@ -210,6 +213,7 @@ class FlatIPIndex:
                              _lib.TS_FLAG_NO_FILTER, _stream_ptr(self.device))
             redone.append(int(failed[i]))
         self._pending.clear()
+        self._pending_passes = 0
         return redone
 
     def reconstruct_n(self, i0: int = 0, n: Optional[int] = None) -> np.ndarray:
