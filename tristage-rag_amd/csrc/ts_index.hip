@@ -498,7 +498,10 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   nsb = std::min(nsb, nblk);
   const int64_t sstride = nblk / nsb;
   const int64_t S = nsb * TS_ROWS_PER_BLOCK;
-  uint32_t m = (uint32_t)((kOversample * (int64_t)k * S + N - 1) / N);
+  // expected survivors per query ~ oversample * k; 3x for large k keeps the worst query of a
+  // batch (about 1.5x the mean) well inside the 16384 candidate slots
+  const int64_t oversample = k > 1024 ? 3 : kOversample;
+  uint32_t m = (uint32_t)((oversample * (int64_t)k * S + N - 1) / N);
   m = std::max(m, kMinSampleRank);
   TS_CHECK(ensure(W.sample, (size_t)nq * S * 4));
   TS_CHECK(ensure(W.cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
