@@ -333,12 +333,11 @@ static int launch_scan_t(const TsLayout& L, const ScanParams& p, int num_cus,
                                160 * 1024));
     attr_set = true;
   }
-  // LDS allows floor(160 KiB / lds) resident workgroups per CU; keep at most
-  // 2 (16 waves per CU) — the kernel is HBM-bound, more waves only add
-  // register pressure.
-  int wg_per_cu = (int)((160 * 1024) / lds);
-  if (wg_per_cu < 1) wg_per_cu = 1;
-  if (wg_per_cu > 2) wg_per_cu = 2;
+  // The fused scan is HBM-bound with one 8-wave workgroup per CU (more waves measured
+  // slower: 16 waves/CU -1.5 %); the short dense scans (sample, small corpora) are
+  // latency-bound and take a second workgroup per CU when LDS allows.
+  int wg_per_cu = 1;
+  if (MODE == SCAN_DENSE && 2 * lds <= 160 * 1024) wg_per_cu = 2;
   int64_t want = (p.nwork + SCAN_WAVES - 1) / SCAN_WAVES;
   int64_t cap = (int64_t)num_cus * wg_per_cu;
   int grid = (int)(want < cap ? want : cap);
