@@ -371,3 +371,14 @@ def test_pipelined_async_searches_match_sync(torch_mod):
     for a, b in zip(acc, exp):
         assert torch.equal(a, b)
     idx.close()
+
+
+def test_k_equals_n_returns_every_row_in_canonical_order():
+    corpus = make_corpus(1000, 96, seed=41, dtype="f16")
+    corpus[500] = corpus[3]                                  # one exact tie
+    queries = make_corpus(4, 96, seed=42, dtype="f16")
+    idx = _index(96, "f16", corpus)
+    D, I = idx.search(queries, 1000)                         # k = N (SURVEY.md §8d adversarial set)
+    assert all(sorted(r.tolist()) == list(range(1000)) for r in I)
+    check_topk(D, I, corpus, queries, 1000)
+    idx.close()
