@@ -283,6 +283,12 @@ def test_mteb_adapter(encoder, tmp_path):
     recs = m.search("neural networks attention", top_k=2)
     assert set(recs[0]) == {"id", "score", "text", "rank", "stage1_score", "stage2_score", "stage3_score"}
     assert recs[0]["rank"] == 1 and recs[0]["score"] == recs[0]["stage3_score"]
+    qs = ["neural networks attention", "human language", "statistics"]
+    batched = m.search_batch(qs, top_k=2, chunk=2)           # batched stage 1 == per-query search
+    for q, b in zip(qs, batched):
+        one = m.search(q, top_k=2)
+        assert [r["id"] for r in one] == [r["id"] for r in b]
+        assert np.allclose([r["score"] for r in one], [r["score"] for r in b], atol=1e-6)
     pairs = [("neural networks attention", DOCS[3]), ("neural networks attention", DOCS[0]), ("human language", DOCS[1])]
     scores = m.predict(pairs)
     assert len(scores) == 3 and all(isinstance(s, float) for s in scores)

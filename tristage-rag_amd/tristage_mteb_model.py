@@ -145,15 +145,7 @@ class TriStageMTEBModel:
         return self._encode_queries(sentences, task_name, **kwargs)
 
     # -- search ----------------------------------------------------------------
-    def search(self, query: str, top_k: int = 10, task_name: str = "") -> List[Dict[str, Any]]:
-        try:
-            out = self.pipeline.search(query, top_k=top_k)
-        except ValueError as e:
-            if "No documents indexed" in str(e):
-                self.logger.warning("Pipeline has no indexed documents. Returning empty results.")
-                return []
-            raise
-        results = out.get("results", []) if isinstance(out, dict) else out
+    def _format(self, results: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         formatted = []
         for i, r in enumerate(results):
             iid = r.get("doc_id", i)
@@ -163,6 +155,31 @@ class TriStageMTEBModel:
                               "stage2_score": r.get("stage2_score", 0.0),
                               "stage3_score": r.get("stage3_score", 0.0)})
         return formatted
+
+    def search(self, query: str, top_k: int = 10, task_name: str = "") -> List[Dict[str, Any]]:
+        try:
+            out = self.pipeline.search(query, top_k=top_k)
+        except ValueError as e:
+            if "No documents indexed" in str(e):
+                self.logger.warning("Pipeline has no indexed documents. Returning empty results.")
+                return []
+            raise
+        return self._format(out.get("results", []) if isinstance(out, dict) else out)
+
+    def search_batch(self, queries: List[str], top_k: int = 10, chunk: int = 64) -> List[List[Dict[str, Any]]]:
+        """Same records as calling :meth:`search` per query, but stage 1 sweeps the corpus once
+        per `chunk` queries (RetrievalPipeline.search_many) instead of once per query."""
+        out: List[List[Dict[str, Any]]] = []
+        for s in range(0, len(queries), chunk):
+            try:
+                res = self.pipeline.search_many(list(queries[s:s + chunk]), top_k=top_k)
+            except ValueError as e:
+                if "No documents indexed" in str(e):
+                    out.extend([[] for _ in queries[s:s + chunk]])
+                    continue
+                raise
+            out.extend(self._format(r.get("results", [])) for r in res)
+        return out
 
     def predict(self, queries, corpus: List[str] = None, top_k: int = 10, task_name: str = "", **kwargs):
         # pattern 1: list of (query, doc[, instruction]) pairs, no corpus -> one score per pair
@@ -192,7 +209,7 @@ class TriStageMTEBModel:
         # patterns 2 and 3: queries (+ optional corpus) -> list of result lists
         if corpus:
             self._ensure_documents_indexed(corpus)
-        return [self.search(q, top_k=top_k, task_name=task_name) for q in queries]
+        return self.search_batch([str(q) for q in queries], top_k=top_k)
 
     @staticmethod
     def _extract_corpus(c):
@@ -221,6 +238,8 @@ class TriStageMTEBModel:
             for off, cid in enumerate(ids):
                 self._doc_id_map[start + off] = cid
         out: Dict[str, Dict[str, float]] = {}
+        qids: List[str] = []
+        texts: List[str] = []
         items = queries.items() if isinstance(queries, dict) else enumerate(queries)
         for i, q in items:
             if isinstance(queries, dict):
@@ -229,7 +248,10 @@ class TriStageMTEBModel:
                 qid, text = str(q.get("_id", i)), q.get("text", "")
             else:
                 qid, text = str(i), str(q)
-            out[qid] = {str(r.get("id", "")): float(r.get("score", 0.0)) for r in self.search(text, top_k=top_k)}
+            qids.append(qid)
+            texts.append(text)
+        for qid, recs in zip(qids, self.search_batch(texts, top_k=top_k)):
+            out[qid] = {str(r.get("id", "")): float(r.get("score", 0.0)) for r in recs}
         return out
 
     def __call__(self, *args, **kwargs):
