@@ -82,7 +82,13 @@ def cpu_baseline(args, torch):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
+    try:  # the SGEMM runs in numpy's BLAS: report the threads THAT pool uses (it may cap below the core count)
+        from threadpoolctl import threadpool_info
+        blas = [int(p["num_threads"]) for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            cores = min(cores, max(blas))
+    except Exception:
+        pass
     k = min(args.k, n)
     oracle.ip_topk_blas(c, q, k)  # warm-up (BLAS thread pool, page faults)
     reps, t_total = 0, 0.0

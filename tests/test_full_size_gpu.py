@@ -96,3 +96,50 @@ def test_headline_config_10m_x_768_on_one_gpu():
         assert len(got ^ want) <= 4                              # only boundary near-ties may differ
         assert torch.allclose(D[qi], Dr[j], atol=1e-3)
     idx.close()
+
+
+def test_cfg4_corpus_50m_x_1024_bf16_on_one_gpu():
+    """BASELINE.json configs[4]'s WHOLE corpus (50 M x 1024 bf16 = 102.4 GB) resident on one
+    MI355X (288 GB): 64-bit addressing of the tiled corpus (16-byte unit 2^32 is row
+    33,554,432), planted rows at both ends and across that boundary, sortedness / uniqueness,
+    filter path == exact dense path, and an independent fp32 torch reference (blocks
+    regenerated from their seeds) for two queries."""
+    import torch
+    from tristage_rag_amd.index import FlatIPIndex
+    n, d, k, B = 50_000_000, 1024, 1000, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~110 GB of free HBM")
+    q = _gen_on_gpu(torch, B, d, 4321, torch.bfloat16)
+    planted = {0: 0, 7: 33_554_431, 8: 33_554_432, 21: 41_000_001, 63: n - 1}
+    chunk = 500_000
+    idx = FlatIPIndex(d, dtype="bf16")
+    idx.reserve(n)
+
+    def block(c):
+        x = _gen_on_gpu(torch, chunk, d, 99_000 + c, torch.bfloat16)
+        for qi, row in planted.items():
+            if c * chunk <= row < (c + 1) * chunk:
+                x[row - c * chunk] = q[qi]
+        return x
+
+    for c in range(n // chunk):
+        idx.add(block(c))
+    assert idx.ntotal == n
+    D, I = idx.search(q, k)
+    assert idx.last_search_info()["path"] == "filter"
+    for qi, row in planted.items():
+        assert int(I[qi, 0]) == row and abs(float(D[qi, 0]) - 1.0) < 4e-3
+    assert bool((D[:, 1:] <= D[:, :-1]).all()) and int(I.min()) >= 0 and int(I.max()) < n
+    assert all(len(set(r.tolist())) == k for r in I.cpu().numpy()[:8])
+    D2, I2 = idx.search(q, k, exact_dense=True)
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    sel = [8, 40]
+    qs = q[sel].float()
+    ref = torch.cat([qs @ block(c).float().T for c in range(n // chunk)], dim=1)   # [2, n] fp32
+    Dr, Ir = torch.topk(ref, k, dim=1)
+    for j, qi in enumerate(sel):
+        got, want = set(I[qi].tolist()), set(Ir[j].tolist())
+        assert len(got ^ want) <= 4                              # only boundary near-ties may differ
+        assert torch.allclose(D[qi], Dr[j], atol=2e-3)
+    idx.close()

@@ -70,6 +70,34 @@ __global__ __launch_bounds__(512) void k_region(const u32x4* p, size_t nblocks, 
   if ((acc[0]^acc[1]^acc[2]^acc[3]) == 0x12345678u) out[0] = 1;
 }
 
+// pattern 3: ROW-MAJOR rows read in MFMA A-fragment order (what a MaxSim kernel over a
+// row-major token store must do): a wave owns a 32-row tile; v_mfma_32x32x16 layout:
+// lane (r = l%32, h = l/32) reads 16 B at row r, byte 32g + 16h  -> 32 rows x 32 B per instruction.
+// RPI = 16: the 16x16x32 layout, lane (r = l%16, q = l/16) reads row r, byte 64g + 16q (16 rows x 64 B).
+template <bool NT, int UNROLL, int RPI>
+__global__ __launch_bounds__(512) void k_rowfrag(const u32x4* p, size_t ntiles, int rowbytes, uint32_t* out) {
+  const int lane = threadIdx.x & 63;
+  const size_t W = (size_t)gridDim.x * (blockDim.x >> 6);
+  size_t t = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  constexpr int PER = 64 / RPI;              // lanes per row per instruction
+  const int r = lane % RPI, c = lane / RPI;
+  const int steps = rowbytes / (16 * PER);
+  u32x4 acc = {0,0,0,0};
+  for (; t < ntiles; t += W) {
+    for (int sub = 0; sub < 32 / RPI; ++sub) {
+      const char* base = (const char*)p + (t * 32 + sub * RPI + r) * (size_t)rowbytes + 16 * c;
+      for (int g = 0; g < steps; g += UNROLL) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) v[i] = ld<NT>((const u32x4*)(base + (size_t)(g + i) * 16 * PER));
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) fold(acc, v[i]);
+      }
+    }
+  }
+  if ((acc[0]^acc[1]^acc[2]^acc[3]) == 0x12345678u) out[0] = 1;
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (argc > 1 ? atof(argv[1]) : 15.36) * 1e9;
   const int blk = 48;  // KiB per block (768 x fp16 x 32 rows)
@@ -88,6 +116,25 @@ int main(int argc, char** argv) {
     }
     printf("%-44s avg %.3f ms  %.1f GB/s   best %.1f GB/s\n", name, sum / reps, units * 1024.0 / (sum / reps) / 1e6, units * 1024.0 / best / 1e6);
   };
+  if (argc > 2) {   // row-major fragment-order reads only
+    const int rowbytes = 1536; const size_t ntiles = units * 1024 / (32 * (size_t)rowbytes);
+    for (int grid : {256, 512, 1024}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "rowfrag 32x32B     grid=%d x512 unroll8", grid);
+      run(nm, [&]{ k_rowfrag<false, 8, 32><<<grid, 512>>>(p, ntiles, rowbytes, out); });
+      snprintf(nm, sizeof nm, "rowfrag 32x32B nt  grid=%d x512 unroll8", grid);
+      run(nm, [&]{ k_rowfrag<true, 8, 32><<<grid, 512>>>(p, ntiles, rowbytes, out); });
+      snprintf(nm, sizeof nm, "rowfrag 16x64B     grid=%d x512 unroll8", grid);
+      run(nm, [&]{ k_rowfrag<false, 8, 16><<<grid, 512>>>(p, ntiles, rowbytes, out); });
+      snprintf(nm, sizeof nm, "rowfrag 16x64B nt  grid=%d x512 unroll8", grid);
+      run(nm, [&]{ k_rowfrag<true, 8, 16><<<grid, 512>>>(p, ntiles, rowbytes, out); });
+      snprintf(nm, sizeof nm, "rowfrag 32x32B nt  grid=%d x256 unroll12", grid * 2);
+      run(nm, [&]{ k_rowfrag<true, 12, 32><<<grid * 2, 256>>>(p, ntiles, rowbytes, out); });
+      snprintf(nm, sizeof nm, "blocked nt (contig) grid=%d x512 unroll8", grid);
+      run(nm, [&]{ k_blocked<true, 8><<<grid, 512>>>(p, nblocks, blk, out); });
+    }
+    return 0;
+  }
   for (int grid : {256, 512, 1024, 2048}) {
     char nm[128];
     snprintf(nm, sizeof nm, "linear      grid=%d x512 unroll8", grid);

@@ -164,3 +164,8 @@ int ts_launch_tau(const float* sample, int64_t ld, uint32_t n, uint32_t m,
 int ts_launch_maxsim(const void* q, int Lq, const void* docs,
                      const int32_t* doc_off, const int64_t* starts, const int32_t* lens,
                      int n_docs, int H, int dtype, int mode, float* out, hipStream_t stream);
+// HBM-bound streaming form for f16/bf16 token matrices (ts_maxsim16.hip).  Returns
+// TS_ERR_UNSUPPORTED without an error string for shapes it does not take.
+int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* doc_off,
+                       const int64_t* starts, const int32_t* lens, int n_docs, int H, int dtype,
+                       int mode, float* out, int device, hipStream_t stream);

@@ -794,6 +794,9 @@ extern "C" int ts_maxsim(const void* q, int32_t Lq, const void* docs, const int3
   }
   DeviceGuard g(device);
   if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  const int st = ts_launch_maxsim16(q, Lq, docs, doc_off, nullptr, nullptr, n_docs, H, dtype, mode, out,
+                                    device, (hipStream_t)stream);
+  if (st != TS_ERR_UNSUPPORTED) return st;
   return ts_launch_maxsim(q, Lq, docs, doc_off, nullptr, nullptr, n_docs, H, dtype, mode, out,
                           (hipStream_t)stream);
 }
@@ -809,6 +812,9 @@ extern "C" int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, c
   }
   DeviceGuard g(device);
   if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  const int st = ts_launch_maxsim16(q, Lq, store, nullptr, starts, lens, n_docs, H, dtype, mode, out,
+                                    device, (hipStream_t)stream);
+  if (st != TS_ERR_UNSUPPORTED) return st;
   return ts_launch_maxsim(q, Lq, store, nullptr, starts, lens, n_docs, H, dtype, mode, out,
                           (hipStream_t)stream);
 }

@@ -1,0 +1,572 @@
+// Stage-2 MaxSim for 16-bit token matrices on gfx950: the HBM-bound streaming form.
+//
+// Same scores as ts_maxsim.hip (reference src/stage2_rescorer.py:167-201 applied to
+// every candidate, loop at :268-276):  for query tokens Q[Lq,H], document tokens D[Ld,H]
+//   S = normalize(Q) . normalize(D)^T,  m_i = max_j S_ij,
+//   maxsim = mean_i m_i            colbert = sum_i softmax(m)_i * m_i
+// but organised like the stage-1 scan, because with a resident token store this step
+// is a pure read of the candidates' token rows (C * Ld * H * 2 bytes per query, ~0.2-0.3 GB
+// at C = 1000): the roofline that bounds it is HBM, not MFMA.  ONE launch per query:
+//
+//   * work item = 32 consecutive token rows of one candidate ("tile").  The tiles of all
+//     candidates form one sequence; persistent wave w owns the contiguous slice
+//     [w*T/W, (w+1)*T/W) of it, so every wave streams the same number of bytes (+-1 tile)
+//     whatever the candidates' lengths are.  Every workgroup computes the tile prefix sums
+//     of the (<= 4096) candidates itself, in LDS, while its query image is in flight — a
+//     separate "prepare" launch cost 8 us + a kernel boundary on a ~40 us kernel.
+//   * the token rows stay ROW-MAJOR where PyTorch wrote them.  A wave reads them
+//     directly in MFMA A-fragment order (lane (r,h): 16 B of row r at byte 32g+16h):
+//     32 rows x 32 B per instruction.  Plain loads (NOT nt: each 128-byte line is
+//     touched by four consecutive instructions; with nt the line is refetched, measured
+//     3.3 vs 6.2 TB/s, tools/bw_probe.hip "rowfrag"), an 8-deep register ring per wave.
+//   * the query tokens (<= 64 per pass) are the stationary operand: staged once per
+//     workgroup into LDS in B-fragment order, lane-linear ds_read_b128.
+//   * v_mfma_f32_32x32x16_{f16,bf16}: accumulator column <-> query token (lane),
+//     accumulator row <-> document token (register), so max over the document's
+//     tokens is an in-lane max over registers.  The rows' squared norms come from the
+//     operand values already in registers (v_dot2c); 1/|d| reaches the accumulator
+//     layout through a 128-byte wave-private LDS transpose.
+//   * per (candidate, query token) maxima are combined across tiles in registers while
+//     a wave stays inside one candidate, then across waves with one uint atomicMax per
+//     lane (order-preserving float key) into a scratch array.  When a wave has finished
+//     streaming it adds its tile counts to per-candidate arrival counters; the wave that
+//     completes a candidate reads the maxima back, writes the score and zeroes the cells,
+//     so the scratch is all-zero again when the launch ends (no init / finish launches).
+#include "ts_common.h"
+#include <algorithm>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef M16_THREADS
+#define M16_THREADS 512
+#endif
+#define M16_WAVES (M16_THREADS / 64)
+#ifndef M16_RING
+#define M16_RING 8      // k steps (1 KiB each) kept in flight per wave
+#endif
+#ifndef M16_GROUP
+#define M16_GROUP 8     // ring slots refilled together.  Issuing the loads that share a 128-byte line
+                        // set back to back matters: refilling one slot per step (GROUP 1) re-misses
+                        // L1 for 3 of the 4 touches of a line: 4.35 TB/s vs 4.76 (GROUP 4) vs 5.09
+                        // (GROUP 8) on 600 MB of candidates (tools/diag_maxsim.sh)
+#endif
+#define M16_NEG (-3.402823466e38f)
+
+#define M16_MAX_DOCS 4096   // candidates per launch (their tile prefix sums live in LDS)
+
+struct Ms16Params {
+  const uint16_t* q;       // [Lq, H]
+  int Lq, H;
+  int s_pad;               // k steps per tile (16 elements each), multiple of M16_RING
+  int lq_pad;              // row stride of `best` (= passes * NQT * 32)
+  int passes;              // gridDim.y: query tokens are taken NQT*32 per pass
+  const uint16_t* docs;    // [rows, H] row-major
+  const int32_t* doc_off;  // packed candidates: [n_docs+1] (or null)
+  const int64_t* starts;   // token store: [n_docs]
+  const int32_t* lens;     //              [n_docs]
+  int n_docs;              // <= M16_MAX_DOCS
+  // scratch, all-zero between launches
+  uint32_t* cnt;           // [n_docs] tiles (x passes) that have been folded into `best`
+  uint32_t* best;          // [n_docs][lq_pad] ordered-uint keys of max_j cos(q_i, d_j); 0 = none
+  int mode;
+  float* out;
+};
+
+// Wave-uniform table reads inside the streaming loop must be SCALAR loads: as vector loads
+// they share vmcnt with the ring and every candidate change would wait for vmcnt(0), i.e.
+// drain the ring (the compiler does not pick s_load by itself once the loop holds atomics).
+__device__ __forceinline__ int32_t m16_sload32(const int32_t* ptr) {
+  int32_t v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+  return v;
+}
+__device__ __forceinline__ int64_t m16_sload64(const int64_t* ptr) {
+  int64_t v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+  return v;
+}
+__device__ __forceinline__ int m16_len_s(const Ms16Params& p, int d) {
+  return p.starts ? m16_sload32(p.lens + d) : (m16_sload32(p.doc_off + d + 1) - m16_sload32(p.doc_off + d));
+}
+__device__ __forceinline__ int64_t m16_start_s(const Ms16Params& p, int d) {
+  return p.starts ? m16_sload64(p.starts + d) : (int64_t)m16_sload32(p.doc_off + d);
+}
+__device__ __forceinline__ int m16_len(const Ms16Params& p, int d) {
+  return p.starts ? p.lens[d] : (p.doc_off[d + 1] - p.doc_off[d]);
+}
+__device__ __forceinline__ int64_t m16_start(const Ms16Params& p, int d) {
+  return p.starts ? p.starts[d] : (int64_t)p.doc_off[d];
+}
+// float -> uint whose unsigned order is the float order; 0 is below every finite value
+__device__ __forceinline__ uint32_t m16_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float m16_unkey(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// sum of squares of the 8 values of one operand register quad.  (Whole-vector casts and
+// constant shuffles only: hipcc 7.2 miscompiles __builtin_bit_cast of a[i] inside an
+// unrolled loop — every iteration reads element 0; see DESIGN.md "Notes".)
+template <int DT> __device__ __forceinline__ float m16_sumsq(const u32x4& a, float s) {
+  if constexpr (DT == TS_F16) {
+    const h8 v = __builtin_bit_cast(h8, a);
+    const h2 p0 = __builtin_shufflevector(v, v, 0, 1), p1 = __builtin_shufflevector(v, v, 2, 3);
+    const h2 p2 = __builtin_shufflevector(v, v, 4, 5), p3 = __builtin_shufflevector(v, v, 6, 7);
+    s = __builtin_amdgcn_fdot2(p0, p0, s, false);
+    s = __builtin_amdgcn_fdot2(p1, p1, s, false);
+    s = __builtin_amdgcn_fdot2(p2, p2, s, false);
+    s = __builtin_amdgcn_fdot2(p3, p3, s, false);
+  } else {
+    const bf8 v = __builtin_bit_cast(bf8, a);
+    const bf2 p0 = __builtin_shufflevector(v, v, 0, 1), p1 = __builtin_shufflevector(v, v, 2, 3);
+    const bf2 p2 = __builtin_shufflevector(v, v, 4, 5), p3 = __builtin_shufflevector(v, v, 6, 7);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, s, false);
+  }
+  return s;
+}
+template <int DT> __device__ __forceinline__ float m16_tofloat(uint16_t x) {
+  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, x);
+  else return __uint_as_float((uint32_t)x << 16);
+}
+template <int DT>
+__device__ __forceinline__ void m16_mma(f32x16& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (DT == TS_F16)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), acc, 0, 0, 0);
+  else
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------
+// 16 bytes of this lane's row for k step g (k = 16g + 8h .. +8).  The load is ALWAYS issued
+// (a load under a lane predicate becomes a branch with s_waitcnt vmcnt(0) behind it, which
+// drains the ring): steps past H re-read unit 0 of the row and are zeroed when consumed.
+template <bool FULL>
+__device__ __forceinline__ u32x4 m16_load(const uint16_t* rowp, int g, int h, int H) {
+  if constexpr (FULL) return *reinterpret_cast<const u32x4*>(rowp + 16 * g);
+  const int off = (16 * g + 8 * h < H) ? 16 * g : 0;
+  return *reinterpret_cast<const u32x4*>(rowp + off);
+}
+template <bool FULL>
+__device__ __forceinline__ u32x4 m16_use(const u32x4& v, int g, int h, int H) {
+  if constexpr (FULL) return v;
+  const bool ok = 16 * g + 8 * h < H;
+  return u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
+}
+
+// ---------------------------------------------------------------------------------
+// The wave that completes candidate d: m_i -> score, then give the cells back as zeros.
+__device__ __forceinline__ void m16_finish_doc(const Ms16Params& p, int d, int lane) {
+  uint32_t* b = p.best + (size_t)d * p.lq_pad;
+  float res;
+  if (p.mode == 0) {
+    float s = 0.f;
+    for (int i = lane; i < p.Lq; i += 64)
+      s += m16_unkey(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    res = s / (float)p.Lq;
+  } else {
+    float mx = M16_NEG;
+    for (int i = lane; i < p.Lq; i += 64)
+      mx = fmaxf(mx, m16_unkey(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float num = 0.f, den = 0.f;
+    for (int i = lane; i < p.Lq; i += 64) {
+      const float v = m16_unkey(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const float e = expf(v - mx);
+      den += e;
+      num += e * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      num += __shfl_xor(num, o, 64);
+      den += __shfl_xor(den, o, 64);
+    }
+    res = num / den;
+  }
+  if (lane == 0) p.out[d] = res;
+  for (int i = lane; i < p.lq_pad; i += 64) __hip_atomic_store(b + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(p.cnt + d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Candidates this wave has left (lane i holds record i): add their tile counts to the arrival
+// counters; whoever brings a counter to its target finishes that candidate.
+__device__ __forceinline__ void m16_flush_records(const Ms16Params& p, int nrec, int rdoc,
+                                                  uint32_t rtiles, uint32_t rneed, int lane) {
+  // Order "my atomicMax are performed" before "my counts are performed" WITHOUT a fence: a
+  // release fence at agent scope is buffer_wbl2 sc1 — a write-back of the whole L2 — and 2048
+  // waves executing it made the kernel 3.5x slower (186 vs 53 us).  All the data involved is
+  // only ever touched by agent-scope atomics, which are performed at the coherence point, and
+  // vmcnt(0) returns when the L2 has acknowledged this wave's atomics.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  asm volatile("" ::: "memory");
+  uint32_t old = 0;
+  if (lane < nrec) old = atomicAdd(p.cnt + rdoc, rtiles);
+  const bool last = lane < nrec && old + rtiles == rneed;  // (consuming `old` waits for the atomic)
+  uint64_t mask = __builtin_amdgcn_ballot_w64(last);
+  asm volatile("" ::: "memory");
+  while (mask) {
+    const int bit = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    m16_finish_doc(p, __builtin_amdgcn_readlane(rdoc, bit), lane);  // agent-scope atomic loads / stores
+  }
+}
+
+// one k step: the row norms and NQT MFMAs on operand `a` of step g
+#if defined(TS_TUNING) && defined(M16_DBG_NOCOMPUTE)  // ablation builds only: loads kept live, no math
+#define M16_STEP(a, g) do { dsq += __uint_as_float(((a)[0] ^ (a)[1] ^ (a)[2] ^ (a)[3]) & 0x007fffffu); } while (0)
+#else
+#define M16_STEP(a, g)                                                                          \
+  do {                                                                                          \
+    dsq = m16_sumsq<DT>((a), dsq);                                                              \
+    _Pragma("unroll") for (int t = 0; t < NQT; ++t)                                             \
+        m16_mma<DT>(acc[t], (a), ql[(size_t)((g) * NQT + t) * 64]);                             \
+  } while (0)
+#endif
+
+template <int DT, int NQT, bool FULL>
+__global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* qlds = reinterpret_cast<u32x4*>(smem);                                  // [s_pad][NQT][64]
+  float* invl = reinterpret_cast<float*>(smem + (size_t)p.s_pad * NQT * 1024);    // [waves][32]
+  int32_t* wsum = reinterpret_cast<int32_t*>(invl + M16_WAVES * 32);              // [waves] (+pad to 64 B)
+  int32_t* prefix = wsum + 16;                                                    // [n_docs+1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * (NQT * 32);  // first query token of this pass
+  const int H = p.H;
+  const int S = p.s_pad;
+
+  // ---- tiles per candidate of this thread's share of the candidates (loads go out first)
+  const int per = (p.n_docs + M16_THREADS - 1) / M16_THREADS;   // <= M16_MAX_DOCS / M16_THREADS
+  const int d0 = min(tid * per, p.n_docs), d1 = min(d0 + per, p.n_docs);
+  int mytiles = 0;
+  for (int d = d0; d < d1; ++d) {
+    const int len = m16_len(p, d);
+    mytiles += len > 0 ? (len + 31) / 32 : 0;
+    if (len <= 0 && blockIdx.x == 0 && blockIdx.y == 0)
+      p.out[d] = 0.f;  // reference: a candidate that cannot be scored keeps 0.0 (:285-291)
+  }
+
+  // ---- Q image: unit (g*NQT + t)*64 + l = Q[q0 + 32t + (l&31)][16g + 8(l>>5) .. +8]
+  // (8 independent L2 reads in flight per thread: one at a time costs ~1 us each)
+  {
+    const int units = S * NQT * 64;
+    for (int u0 = tid; u0 < units; u0 += 8 * M16_THREADS) {
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + j * M16_THREADS;
+        const int l = u & 63, t = (u >> 6) % NQT, g = (u >> 6) / NQT;
+        const int qi = q0 + 32 * t + (l & 31), k = 16 * g + 8 * (l >> 5);
+        const bool ok = u < units && qi < p.Lq && k < H;
+        // always-issued load from a valid address, zeroed afterwards (no branch around the load)
+        const u32x4 x = *reinterpret_cast<const u32x4*>(p.q + (ok ? (size_t)qi * H + k : 0));
+        v[j] = u32x4{ok ? x[0] : 0u, ok ? x[1] : 0u, ok ? x[2] : 0u, ok ? x[3] : 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u = u0 + j * M16_THREADS;
+        if (u < units) qlds[u] = v[j];
+      }
+    }
+  }
+  // Explicit vmcnt(0): the stores above sit under a lane predicate, so on their skip path the
+  // compiler's scoreboard still counts the staging loads as pending and would put a
+  // vmcnt(0) in front of the first reuse of their registers — inside the tile loop, where it
+  // drains the ring once per tile.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+
+  // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + 8 wave totals)
+  int incl = mytiles;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, T = 0;
+#pragma unroll
+  for (int w = 0; w < M16_WAVES; ++w) {
+    const int x = wsum[w];
+    base += (w < wave) ? x : 0;
+    T += x;
+  }
+  {
+    int run = base + incl - mytiles;
+    for (int d = d0; d < d1; ++d) {
+      prefix[d] = run;
+      const int len = m16_len(p, d);  // (L1/L2 hit: read a moment ago)
+      run += len > 0 ? (len + 31) / 32 : 0;
+    }
+    if (tid == 0) prefix[p.n_docs] = T;
+  }
+  __syncthreads();
+
+  // ---- this wave's slice of the tile sequence (wave-major numbering spreads the longer
+  // slices over all workgroups)
+  const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
+  const int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
+  const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
+  if (lo >= hi) return;  // (no block-level barrier below)
+
+  int doc, tile, len;
+  int64_t start;
+  {
+    int a = 0, b = p.n_docs;  // prefix[a] <= lo < prefix[b]
+    while (b - a > 1) {
+      const int m = (a + b) >> 1;
+      if ((int64_t)prefix[m] <= lo) a = m; else b = m;
+    }
+    doc = __builtin_amdgcn_readfirstlane(a);
+    tile = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
+    len = m16_len_s(p, doc);
+    start = m16_start_s(p, doc);
+  }
+  const uint16_t* cur;
+  u32x4 ring[M16_RING];
+  {
+    const int rows = min(32, len - tile * 32);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 8 * h);
+#pragma unroll
+    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
+  }
+
+  const u32x4* ql = qlds + lane;
+  // ---- 1/|q_i| of this lane's query token(s), from the image (fixed order: deterministic)
+  float invq[NQT];
+  {
+    float qsq[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) qsq[t] = 0.f;
+    for (int g = 0; g < S; ++g)
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) qsq[t] = m16_sumsq<DT>(ql[(size_t)(g * NQT + t) * 64], qsq[t]);
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+      qsq[t] += __shfl_xor(qsq[t], 32, 64);
+      invq[t] = 1.0f / fmaxf(sqrtf(qsq[t]), 1e-12f);
+    }
+  }
+
+  float* myinv = invl + wave * 32;
+  float best[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) best[t] = M16_NEG;
+  // candidates left behind: lane i keeps record i
+  int nrec = 0, rdoc = 0;
+  uint32_t rtiles = 0, rneed = 0, run_tiles = 0;
+
+  for (int64_t it = lo; it < hi; ++it) {
+    // ---- next item of the slice (wave-uniform)
+    const bool has_next = it + 1 < hi;
+    int ndoc = doc, ntile = tile + 1, nlen = len;
+    int64_t nstart = start;
+    if (has_next && ntile * 32 >= len) {
+      ntile = 0;
+      ndoc = __builtin_amdgcn_readfirstlane(ndoc);
+      do { ++ndoc; nlen = m16_len_s(p, ndoc); } while (nlen <= 0);  // a later tile exists: terminates
+      nstart = m16_start_s(p, ndoc);
+    }
+    const uint16_t* nxt = cur;
+    if (has_next) {
+      const int nrows = min(32, nlen - ntile * 32);
+      nxt = p.docs + ((size_t)(nstart + ntile * 32 + min(r, nrows - 1)) * H + 8 * h);
+    }
+
+    f32x16 acc[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[t][x] = 0.f;
+    float dsq = 0.f;
+
+    int g0 = 0;
+    for (; g0 < S - M16_RING; g0 += M16_RING) {
+#pragma unroll
+      for (int i = 0; i < M16_RING; ++i) {
+        const u32x4 a = m16_use<FULL>(ring[i], g0 + i, h, H);
+        M16_STEP(a, g0 + i);
+        if ((i + 1) % M16_GROUP == 0) {  // refill the group of slots just consumed
+#pragma unroll
+          for (int j = i + 1 - M16_GROUP; j <= i; ++j) ring[j] = m16_load<FULL>(cur, g0 + j + M16_RING, h, H);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < M16_RING; ++i) {  // tail: refill from the next tile
+      const u32x4 a = m16_use<FULL>(ring[i], g0 + i, h, H);
+      M16_STEP(a, g0 + i);
+      if ((i + 1) % M16_GROUP == 0) {  // (nxt = cur after the slice's last tile: harmless re-read)
+#pragma unroll
+        for (int j = i + 1 - M16_GROUP; j <= i; ++j) ring[j] = m16_load<FULL>(nxt, j, h, H);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- 1/|d_j| of the tile's rows: lane (r, *) knows row r, accumulator register x of
+    // a lane holds row (x&3) + 8(x>>2) + 4h -> transpose through wave-private LDS
+    dsq += __shfl_xor(dsq, 32, 64);
+    if (h == 0) myinv[r] = 1.0f / fmaxf(sqrtf(dsq), 1e-12f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int x4 = 0; x4 < 4; ++x4) {
+      const float4 iv = *reinterpret_cast<const float4*>(myinv + 8 * x4 + 4 * h);
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const float a0 = acc[t][4 * x4 + 0] * iv.x, a1 = acc[t][4 * x4 + 1] * iv.y;
+        const float a2 = acc[t][4 * x4 + 2] * iv.z, a3 = acc[t][4 * x4 + 3] * iv.w;
+        best[t] = fmaxf(best[t], fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ++run_tiles;
+
+    // ---- leaving this candidate (or the slice): publish the maxima, remember the candidate
+    if (!has_next || ndoc != doc) {
+#pragma unroll
+      for (int t = 0; t < NQT; ++t) {
+        const float m = fmaxf(best[t], __shfl_xor(best[t], 32, 64)) * invq[t];
+        const int qi = q0 + 32 * t + r;
+        if (h == 0 && qi < p.Lq) atomicMax(p.best + (size_t)doc * p.lq_pad + qi, m16_key(m));
+        best[t] = M16_NEG;
+      }
+      if (lane == nrec) {
+        rdoc = doc;
+        rtiles = run_tiles;
+        rneed = (uint32_t)p.passes * (uint32_t)((len + 31) / 32);
+      }
+      run_tiles = 0;
+      if (++nrec == 64) {  // (only with very many tiny candidates per wave)
+        m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane);
+        nrec = 0;
+      }
+    }
+    doc = ndoc; tile = ntile; len = nlen; start = nstart; cur = nxt;
+  }
+  if (nrec) m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane);
+}
+
+// ---------------------------------------------------------------------------------
+// scratch per (device, stream): calls on one stream are ordered, so the buffer can be
+// reused; calls on different streams get different buffers.  Invariant: all-zero whenever
+// no launch is pending on it (the kernel returns every cell it used to zero).
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include <utility>
+namespace {
+struct Scratch { void* ptr = nullptr; size_t bytes = 0; };
+std::mutex g_mu;
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+int g_cus[64];
+
+int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Scratch& s = g_scratch[{device, stream}];
+  if (s.bytes < bytes) {
+    if (s.ptr) {
+      TS_HIP(hipStreamSynchronize(stream));  // earlier launches may still use it
+      TS_HIP(hipFree(s.ptr));
+      s.ptr = nullptr; s.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 2 + 4096;
+    TS_HIP(hipMalloc(&s.ptr, want));
+    s.bytes = want;
+    TS_HIP(hipMemsetAsync(s.ptr, 0, want, stream));
+  }
+  *out = s.ptr;
+  return TS_OK;
+}
+}  // namespace
+
+template <int DT, int NQT, bool FULL>
+static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s) {
+  auto kern = maxsim16_kernel<DT, NQT, FULL>;
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid, p.passes), dim3(M16_THREADS), lds, s, p);
+  TS_HIP(hipGetLastError());
+  return TS_OK;
+}
+
+// returns TS_ERR_UNSUPPORTED (without setting an error) when the shape is not one this
+// kernel takes; the caller then uses the general kernel of ts_maxsim.hip
+int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* doc_off,
+                       const int64_t* starts, const int32_t* lens, int n_docs, int H, int dtype,
+                       int mode, float* out, int device, hipStream_t stream) {
+  if (dtype != TS_F16 && dtype != TS_BF16) return TS_ERR_UNSUPPORTED;
+  if (Lq <= 0 || n_docs <= 0 || (H % 8) != 0) return TS_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(docs)) & 15) return TS_ERR_UNSUPPORTED;
+  const int s_real = (H + 15) / 16;
+  const int s_pad = ((s_real + M16_RING - 1) / M16_RING) * M16_RING;
+  const size_t lds_cap = 156 * 1024;
+  const size_t extra = M16_WAVES * 32 * sizeof(float) + 64 + ((size_t)M16_MAX_DOCS + 1) * 4 + 12;
+  const int nqt = (Lq > 32 && (size_t)s_pad * 2 * 1024 + extra <= lds_cap) ? 2 : 1;
+  const size_t lds = (size_t)s_pad * nqt * 1024 + extra;
+  if (lds > lds_cap) return TS_ERR_UNSUPPORTED;
+  const int passes = (Lq + nqt * 32 - 1) / (nqt * 32);
+  const int lq_pad = passes * nqt * 32;
+
+  if (device < 0 || device >= 64) return TS_ERR_UNSUPPORTED;
+  if (g_cus[device] == 0) {
+    int n = 0;
+    TS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    g_cus[device] = n > 0 ? n : 256;
+  }
+  int grid = g_cus[device];
+#ifdef TS_TUNING
+  if (const char* e = getenv("TS_M16_GRIDMUL")) grid = (int)(grid * atof(e));
+#endif
+
+  Ms16Params p;
+  p.q = (const uint16_t*)q; p.Lq = Lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
+  p.docs = (const uint16_t*)docs; p.mode = mode;
+  const int chunk_max = M16_MAX_DOCS;
+  const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
+  void* ws = nullptr;
+  TS_CHECK(scratch_get(device, stream, cells * 4, &ws));
+  const bool full = (H % (16 * M16_RING)) == 0;  // no k step past H: unpredicated loads
+  for (int c0 = 0; c0 < n_docs; c0 += chunk_max) {   // (one launch unless > 4096 candidates)
+    const int n = std::min(chunk_max, n_docs - c0);
+    p.n_docs = n;
+    p.doc_off = doc_off ? doc_off + c0 : nullptr;
+    p.starts = starts ? starts + c0 : nullptr;
+    p.lens = lens ? lens + c0 : nullptr;
+    p.out = out + c0;
+    p.cnt = (uint32_t*)ws;
+    p.best = p.cnt + n;
+#define M16_GO(DT_, NQT_)                                                       \
+  (full ? launch_main<DT_, NQT_, true>(p, grid, lds, stream)                    \
+        : launch_main<DT_, NQT_, false>(p, grid, lds, stream))
+    if (dtype == TS_F16) {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
+    } else {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
+    }
+#undef M16_GO
+  }
+  return TS_OK;
+}
