@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--store", action="store_true",
                     help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
     ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
+    ap.add_argument("--many", type=int, default=0,
+                    help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -54,8 +56,16 @@ def main():
         for q in queries:                     # fill the cache (a real deployment fills it at add time)
             p.search(q)
     torch.cuda.synchronize()
+    if args.many:
+        p.search_many(queries[: args.many])   # warm-up of the batched shapes
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = [p.search(q) for q in queries]
+    if args.many:
+        outs = []
+        for s in range(0, len(queries), args.many):
+            outs.extend(p.search_many(queries[s: s + args.many]))
+    else:
+        outs = [p.search(q) for q in queries]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = {k: float(np.mean([o["timing"][k] for o in outs])) for k in ("stage1_time", "stage2_time", "stage3_time", "total_time")}
@@ -68,7 +78,8 @@ def main():
         "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
-                   "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs},
+                   "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
+                   "queries_per_search_many": args.many},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,

@@ -169,6 +169,17 @@ int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, const int64_
                       const int32_t* lens, int32_t n_docs, int32_t H, int32_t dtype,
                       int32_t mode, float* out, int32_t device, void* stream);
 
+/* The same for several queries in ONE launch (the batched caller: RetrievalPipeline.search_many):
+ * query j has tokens [q_off[j], q_off[j+1]) of q [sum Lq, H] and candidates
+ * [cand_off[j], cand_off[j+1]) of starts / lens / out.  q_off and cand_off are HOST arrays of
+ * nq+1 int32 starting at 0; everything else is device memory.  A single query's launch is
+ * dominated by fixed costs (~25 of ~50 us at 1000 candidates); batched, they overlap with the
+ * other queries' streaming.                                                              */
+int ts_maxsim_indexed_batch(const void* q, const int32_t* q_off, int32_t nq, const void* store,
+                            const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
+                            int32_t H, int32_t dtype, int32_t mode, float* out, int32_t device,
+                            void* stream);
+
 /* ---- BM25 (the lexical half of stage 1) ---------------------------------------
  * replaces BM25Index.search (reference src/stage1_retriever.py:103-112, called at
  * :385-388): same float64 arithmetic and ordering (score desc, doc id asc), but the

@@ -58,3 +58,10 @@ def oracle_maxsim_indexed(q, store, starts, lens, mode="maxsim"):
     st = store.detach().cpu().float().numpy()
     docs = [st[int(a): int(a) + int(n)] for a, n in zip(starts.cpu().tolist(), lens.cpu().tolist())]
     return torch.from_numpy(oracle.maxsim_scores(q.detach().cpu().float().numpy(), docs, mode))
+
+
+def oracle_maxsim_indexed_batch(q_packed, q_off, store, starts, lens, c_off, mode="maxsim"):
+    out = [oracle_maxsim_indexed(q_packed[q_off[j]:q_off[j + 1]], store, starts[c_off[j]:c_off[j + 1]],
+                                 lens[c_off[j]:c_off[j + 1]], mode)
+           for j in range(len(q_off) - 1) if c_off[j + 1] > c_off[j]]
+    return torch.cat(out) if out else torch.zeros(0)

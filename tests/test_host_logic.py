@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from doubles import OracleIndex, oracle_maxsim, oracle_maxsim_indexed
+from doubles import OracleIndex, oracle_maxsim, oracle_maxsim_indexed, oracle_maxsim_indexed_batch
 from tristage_rag_amd.embedding_service import EmbeddingConfig, EmbeddingService
 from tristage_rag_amd.encoders import CrossEncoderModel, HashTokenizer, SentenceEncoder
 from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
@@ -235,7 +235,12 @@ def test_pipeline_search_contract(encoder, tmp_path):
     many = p.search_many(["neural networks attention", "language models"])
     seq = p.batch_search(["neural networks attention", "language models"])
     for a, b in zip(many, seq):
-        assert [(x["doc_id"], x["stage3_score"]) for x in a["results"]] == [(x["doc_id"], x["stage3_score"]) for x in b["results"]]
+        assert [x["doc_id"] for x in a["results"]] == [x["doc_id"] for x in b["results"]]
+        for x, y in zip(a["results"], b["results"]):     # batched forwards: padding noise only
+            assert x["stage3_score"] == pytest.approx(y["stage3_score"], abs=1e-5)
+            assert x["stage2_score"] == pytest.approx(y["stage2_score"], abs=1e-5)
+        assert set(a) == set(b) and set(a["timing"]) == set(b["timing"])
+    assert p.search_many([]) == []
     info = p.get_pipeline_info()
     assert info["stages_initialized"] == {"stage1": True, "stage2": True, "stage3": True}
     assert info["stage1_stats"]["total_documents"] == 5
@@ -370,7 +375,8 @@ def test_chunk_text_and_three_stage_system(encoder, tmp_path):
 def test_stage2_token_store_matches_reencoding():
     cfg = Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=10, batch_size=2,
                        precompute_document_embeddings=True)
-    sc = ColBERTScorer(cfg, maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed)
+    sc = ColBERTScorer(cfg, maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed,
+                       maxsim_indexed_batch_fn=oracle_maxsim_indexed_batch)
     cands = [{"doc_id": 100 + i, "document": d} for i, d in enumerate(DOCS)]
     plain = sc.rescore_candidates("neural attention", cands)          # store empty -> encode path
     sc.index_documents(DOCS[:3], 100)
@@ -384,3 +390,33 @@ def test_stage2_token_store_matches_reencoding():
         assert a[k] == pytest.approx(b[k], abs=1e-5)                   # batch-padding noise only
     mixed = sc.rescore_candidates("neural attention", cands + [{"doc_id": 999, "document": "not stored"}])
     assert len(mixed) == 6                                             # unknown id -> encode path for all
+    # several queries at once: one padded query forward + one (batched) MaxSim call
+    qs = ["neural attention", "human language understanding and more words", "statistics"]
+    lists = [cands[::-1], [], cands[:2]]
+    many = sc.rescore_many(qs, lists)
+    assert many[1] == [] and len(many[2]) == 2
+    for q, cl, got in zip(qs, lists, many):
+        want = sc.rescore_candidates(q, cl) if cl else []
+        assert [x["doc_id"] for x in got] == [x["doc_id"] for x in want]
+        for x, y in zip(got, want):
+            assert x["stage2_score"] == pytest.approx(y["stage2_score"], abs=1e-5) and x["stage"] == "stage2"
+    fallback = sc.rescore_many(qs[:1], [cands + [{"doc_id": 999, "document": "not stored"}]])
+    assert len(fallback[0]) == 6
+
+
+def test_stage3_rerank_many_equals_per_query_rerank():
+    cfg = Stage3Config(model_name="random:tiny", device="cpu", top_k_final=3, batch_size=2, many_batch_size=4)
+    rr = AdaptiveCrossEncoderReranker(cfg)
+    cands = [{"doc_id": i, "document": d, "score": 1.0} for i, d in enumerate(DOCS)]
+    qs = ["neural networks attention", "language", "x"]
+    lists = [cands, [], cands[1:4]]
+    many = rr.rerank_many(qs, lists)
+    assert many[1] == []
+    for q, cl, got in zip(qs, lists, many):
+        want = rr.rerank(q, cl) if cl else []
+        assert [x["doc_id"] for x in got] == [x["doc_id"] for x in want]
+        for x, y in zip(got, want):
+            assert x["stage3_score"] == pytest.approx(y["stage3_score"], abs=1e-5) and x["stage"] == "stage3"
+    assert rr.config.batch_size == 2
+    with pytest.raises(ValueError):
+        rr.rerank_many(["a"], [])

@@ -323,6 +323,41 @@ def test_maxsim_indexed_reads_token_store_in_place(torch_mod, dtype):
                                atol=2e-6 if dtype == "f32" else 1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("dtype,H,lqs", [("bf16", 768, (5, 32, 17, 1)), ("f16", 384, (70, 9, 33, 150)),
+                                         ("bf16", 96, (12, 40)), ("f32", 64, (7, 20))])
+def test_maxsim_batch_of_queries_in_one_launch(torch_mod, dtype, H, lqs):
+    """ts_maxsim_indexed_batch: ragged queries and candidate lists (incl. an empty list and
+    empty candidates) against the oracle, and bit-identical to per-query calls."""
+    torch = torch_mod
+    from tristage_rag_amd.index import maxsim_indexed, maxsim_indexed_batch
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    rng = np.random.default_rng(len(lqs) * H)
+    n_store = 400
+    lens = rng.integers(0, 193, size=n_store)
+    store = oracle.quantize(rng.standard_normal((int(lens.sum()) + 8, H)).astype(np.float32), dtype)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    ncand = [300, 0, 57, 1][: len(lqs)]
+    picks = [rng.permutation(n_store)[:c] for c in ncand]
+    qs = [oracle.quantize(rng.standard_normal((L, H)).astype(np.float32), dtype) for L in lqs]
+    q_off = np.concatenate([[0], np.cumsum(lqs)]).astype(np.int32)
+    c_off = np.concatenate([[0], np.cumsum(ncand)]).astype(np.int32)
+    pk = np.concatenate(picks).astype(np.int64)
+    tq = torch.from_numpy(np.concatenate(qs, 0)).cuda().to(tdt)
+    ts = torch.from_numpy(store).cuda().to(tdt)
+    t_starts, t_lens = torch.from_numpy(starts[pk]).cuda(), torch.from_numpy(lens[pk].astype(np.int32)).cuda()
+    for mode in ("maxsim", "colbert"):
+        got = maxsim_indexed_batch(tq, q_off, ts, t_starts, t_lens, c_off, mode=mode)
+        for j, q in enumerate(qs):
+            a, b = c_off[j], c_off[j + 1]
+            docs = [store[starts[i]: starts[i] + lens[i]] for i in picks[j]]
+            if docs:
+                np.testing.assert_allclose(got[a:b].cpu().numpy(), oracle.maxsim_scores(q, docs, mode),
+                                           atol=2e-6 if dtype == "f32" else 1e-5, rtol=0)
+                one = maxsim_indexed(tq[q_off[j]:q_off[j + 1]], ts, t_starts[a:b], t_lens[a:b], mode=mode)
+                # max and the per-tile arithmetic do not depend on how tiles are sliced over waves
+                assert torch.equal(one, got[a:b])
+
+
 @pytest.mark.parametrize("k,path", [(2048, "filter"), (3000, "dense")])
 def test_largest_k_on_each_path(k, path):
     corpus = make_corpus(120_000, 64, seed=31, dtype="f16")

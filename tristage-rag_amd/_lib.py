@@ -48,6 +48,8 @@ SIGNATURES = {
                             c_int32, c_void_p, c_int32, c_void_p]),
     "ts_maxsim_indexed": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                     c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_maxsim_indexed_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "ts_bm25_create": (c_int32, [c_int32, POINTER(c_void_p)]),
     "ts_bm25_destroy": (c_int32, [c_void_p]),
     "ts_bm25_set_index": (c_int32, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

@@ -169,3 +169,6 @@ int ts_launch_maxsim(const void* q, int Lq, const void* docs,
 int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* doc_off,
                        const int64_t* starts, const int32_t* lens, int n_docs, int H, int dtype,
                        int mode, float* out, int device, hipStream_t stream);
+int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const void* store,
+                             const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
+                             int H, int dtype, int mode, float* out, int device, hipStream_t stream);

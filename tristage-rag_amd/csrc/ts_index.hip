@@ -818,3 +818,35 @@ extern "C" int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, c
   return ts_launch_maxsim(q, Lq, store, nullptr, starts, lens, n_docs, H, dtype, mode, out,
                           (hipStream_t)stream);
 }
+
+extern "C" int ts_maxsim_indexed_batch(const void* q, const int32_t* q_off, int32_t nq, const void* store,
+                                       const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
+                                       int32_t H, int32_t dtype, int32_t mode, float* out, int32_t device,
+                                       void* stream) {
+  if (nq == 0) return TS_OK;
+  if (!q || !q_off || !store || !starts || !lens || !cand_off || !out || nq < 0 || H <= 0 ||
+      !dtype_ok(dtype) || (mode != 0 && mode != 1)) {
+    ts_set_error("bad arguments to maxsim_indexed_batch");
+    return TS_ERR_INVALID;
+  }
+  for (int j = 0; j < nq; ++j)
+    if (q_off[j + 1] < q_off[j] || cand_off[j + 1] < cand_off[j]) {
+      ts_set_error("maxsim_indexed_batch: offsets must be non-decreasing");
+      return TS_ERR_INVALID;
+    }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  const int st = ts_launch_maxsim16_batch(q, q_off, nq, store, starts, lens, cand_off, H, dtype, mode, out,
+                                          device, (hipStream_t)stream);
+  if (st != TS_ERR_UNSUPPORTED) return st;
+  // shapes the one-launch form does not take: query by query
+  const size_t esize = (dtype == TS_F32) ? 4 : 2;
+  for (int j = 0; j < nq; ++j) {
+    const int nc = cand_off[j + 1] - cand_off[j];
+    if (nc == 0) continue;
+    TS_CHECK(ts_maxsim_indexed((const char*)q + (size_t)q_off[j] * H * esize, q_off[j + 1] - q_off[j], store,
+                               starts + cand_off[j], lens + cand_off[j], nc, H, dtype, mode,
+                               out + cand_off[j], device, stream));
+  }
+  return TS_OK;
+}

@@ -70,6 +70,10 @@ struct Ms16Params {
   const int64_t* starts;   // token store: [n_docs]
   const int32_t* lens;     //              [n_docs]
   int n_docs;              // <= M16_MAX_DOCS
+  // several queries in one launch (blockIdx.z = query): query j owns query tokens
+  // [q_off[j], q_off[j+1]) of q and candidates [cand_off[j], cand_off[j+1]) of starts/lens/out
+  const int32_t* q_off;    // device [nq+1] or null
+  const int32_t* cand_off; // device [nq+1]
   // scratch, all-zero between launches
   uint32_t* cnt;           // [n_docs] tiles (x passes) that have been folded into `best`
   uint32_t* best;          // [n_docs][lq_pad] ordered-uint keys of max_j cos(q_i, d_j); 0 = none
@@ -236,7 +240,20 @@ __device__ __forceinline__ void m16_flush_records(const Ms16Params& p, int nrec,
 #endif
 
 template <int DT, int NQT, bool FULL>
-__global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params p) {
+__global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
+  Ms16Params p = pin;
+  if (pin.q_off) {  // one of several queries: narrow every array to this query's part
+    const int qj = blockIdx.z;
+    const int qa = pin.q_off[qj], ca = pin.cand_off[qj];
+    p.Lq = pin.q_off[qj + 1] - qa;
+    p.n_docs = pin.cand_off[qj + 1] - ca;
+    p.q = pin.q + (size_t)qa * pin.H;
+    p.starts += ca; p.lens += ca; p.out += ca;
+    p.cnt += ca;
+    p.best += (size_t)ca * pin.lq_pad;
+    p.passes = (p.Lq + NQT * 32 - 1) / (NQT * 32);
+    if ((int)blockIdx.y >= p.passes || p.n_docs <= 0) return;  // (uniform for the workgroup)
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* qlds = reinterpret_cast<u32x4*>(smem);                                  // [s_pad][NQT][64]
   float* invl = reinterpret_cast<float*>(smem + (size_t)p.s_pad * NQT * 1024);    // [waves][32]
@@ -479,9 +496,10 @@ std::mutex g_mu;
 std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
 int g_cus[64];
 
-int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
+// kind 0: the self-cleaning arrays (zero between launches); kind 1: plain temporary
+int scratch_get(int device, hipStream_t stream, size_t bytes, void** out, int kind = 0) {
   std::lock_guard<std::mutex> lk(g_mu);
-  Scratch& s = g_scratch[{device, stream}];
+  Scratch& s = g_scratch[{device * 2 + kind, stream}];
   if (s.bytes < bytes) {
     if (s.ptr) {
       TS_HIP(hipStreamSynchronize(stream));  // earlier launches may still use it
@@ -499,7 +517,7 @@ int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
 }  // namespace
 
 template <int DT, int NQT, bool FULL>
-static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s) {
+static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s, int nq = 1) {
   auto kern = maxsim16_kernel<DT, NQT, FULL>;
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
@@ -507,7 +525,7 @@ static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s)
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid, p.passes), dim3(M16_THREADS), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid, p.passes, nq), dim3(M16_THREADS), lds, s, p);
   TS_HIP(hipGetLastError());
   return TS_OK;
 }
@@ -543,7 +561,7 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
 
   Ms16Params p;
   p.q = (const uint16_t*)q; p.Lq = Lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
-  p.docs = (const uint16_t*)docs; p.mode = mode;
+  p.docs = (const uint16_t*)docs; p.mode = mode; p.q_off = nullptr; p.cand_off = nullptr;
   const int chunk_max = M16_MAX_DOCS;
   const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
   void* ws = nullptr;
@@ -568,5 +586,73 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
     }
 #undef M16_GO
   }
+  return TS_OK;
+}
+
+// Several queries, one launch (ts_maxsim_indexed_batch): the per-query fixed costs (launch,
+// query image, prefix sums, completion round trips: ~25 us of a ~50 us single-query launch)
+// overlap with other queries' streaming.  q_off / cand_off are HOST arrays.
+int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const void* store,
+                             const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
+                             int H, int dtype, int mode, float* out, int device, hipStream_t stream) {
+  if (dtype != TS_F16 && dtype != TS_BF16) return TS_ERR_UNSUPPORTED;
+  if (nq <= 0 || (H % 8) != 0) return TS_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(store)) & 15) return TS_ERR_UNSUPPORTED;
+  int max_lq = 0, max_cand = 0;
+  for (int j = 0; j < nq; ++j) {
+    const int lq = q_off[j + 1] - q_off[j], nc = cand_off[j + 1] - cand_off[j];
+    if (lq <= 0 || nc < 0 || nc > M16_MAX_DOCS) return TS_ERR_UNSUPPORTED;
+    max_lq = std::max(max_lq, lq);
+    max_cand = std::max(max_cand, nc);
+  }
+  const int64_t n_pairs = (int64_t)cand_off[nq] - cand_off[0];
+  if (n_pairs <= 0) return TS_OK;
+  if (q_off[0] != 0 || cand_off[0] != 0) return TS_ERR_UNSUPPORTED;
+  const int s_real = (H + 15) / 16;
+  const int s_pad = ((s_real + M16_RING - 1) / M16_RING) * M16_RING;
+  const size_t lds_cap = 156 * 1024;
+  const size_t extra = M16_WAVES * 32 * sizeof(float) + 64 + ((size_t)M16_MAX_DOCS + 1) * 4 + 12;
+  const int nqt = (max_lq > 32 && (size_t)s_pad * 2 * 1024 + extra <= lds_cap) ? 2 : 1;
+  const size_t lds = (size_t)s_pad * nqt * 1024 + extra;
+  if (lds > lds_cap) return TS_ERR_UNSUPPORTED;
+  const int passes = (max_lq + nqt * 32 - 1) / (nqt * 32);
+  const int lq_pad = passes * nqt * 32;
+  if (device < 0 || device >= 64) return TS_ERR_UNSUPPORTED;
+  if (g_cus[device] == 0) {
+    int n = 0;
+    TS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    g_cus[device] = n > 0 ? n : 256;
+  }
+  // workgroups per query: ~8 tiles per wave (a candidate is ~4 tiles), at most one per CU
+  int grid = nq == 1 ? g_cus[device] : std::min(g_cus[device], std::max(1, (max_cand + 15) / 16));
+#ifdef TS_TUNING
+  if (const char* e = getenv("TS_M16_BATCH_GRID")) grid = atoi(e);
+#endif
+
+  void* ws = nullptr;
+  TS_CHECK(scratch_get(device, stream, (size_t)n_pairs * (1 + (size_t)lq_pad) * 4, &ws));
+  void* meta = nullptr;
+  const size_t mbytes = (size_t)(nq + 1) * 4;
+  TS_CHECK(scratch_get(device, stream, 2 * mbytes, &meta, 1));
+  TS_HIP(hipMemcpyAsync(meta, q_off, mbytes, hipMemcpyHostToDevice, stream));
+  TS_HIP(hipMemcpyAsync((char*)meta + mbytes, cand_off, mbytes, hipMemcpyHostToDevice, stream));
+
+  Ms16Params p;
+  p.q = (const uint16_t*)q; p.Lq = max_lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
+  p.docs = (const uint16_t*)store; p.doc_off = nullptr; p.starts = starts; p.lens = lens;
+  p.n_docs = max_cand; p.mode = mode; p.out = out;
+  p.q_off = (const int32_t*)meta; p.cand_off = (const int32_t*)((char*)meta + mbytes);
+  p.cnt = (uint32_t*)ws;
+  p.best = p.cnt + n_pairs;
+  const bool full = (H % (16 * M16_RING)) == 0;
+#define M16_GO(DT_, NQT_)                                                       \
+  (full ? launch_main<DT_, NQT_, true>(p, grid, lds, stream, nq)                \
+        : launch_main<DT_, NQT_, false>(p, grid, lds, stream, nq))
+  if (dtype == TS_F16) {
+    if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
+  } else {
+    if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
+  }
+#undef M16_GO
   return TS_OK;
 }

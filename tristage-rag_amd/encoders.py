@@ -393,7 +393,9 @@ class CrossEncoderModel:
         length-sorted order like CrossEncoder.predict."""
         pairs = [list(p) for p in pairs]
         order = np.argsort([-(len(p[0]) + len(p[1])) for p in pairs], kind="stable")
-        out: List[Optional[torch.Tensor]] = [None] * len(pairs)
+        if not pairs:
+            return torch.zeros((0, self.num_labels), device=self.device)
+        res = torch.empty((len(pairs), self.num_labels), dtype=torch.float32, device=self.device)
         for s in range(0, len(pairs), batch_size):
             idx = order[s:s + batch_size]
             enc = self.tokenizer([pairs[i][0] for i in idx], [pairs[i][1] for i in idx], truncation=True,
@@ -401,9 +403,8 @@ class CrossEncoderModel:
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             with _autocast(self.device, self.use_amp, self.amp_dtype):
                 lg = self.model(**enc).logits.float()
-            for j, i in enumerate(idx):
-                out[i] = lg[j]
-        return torch.stack(out) if out else torch.zeros((0, self.num_labels), device=self.device)
+            res[torch.as_tensor(np.ascontiguousarray(idx), device=self.device)] = lg.reshape(len(idx), -1)
+        return res
 
     def predict(self, sentences: Sequence[Sequence[str]], batch_size: int = 32,
                 show_progress_bar: bool = False, **_) -> np.ndarray:

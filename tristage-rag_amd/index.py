@@ -339,3 +339,40 @@ def maxsim_indexed(q, store, starts, lens, mode: str = "maxsim"):
                                      0 if mode == "maxsim" else 1, ctypes.c_void_p(out.data_ptr()), dev,
                                      ctypes.c_void_p(_stream_ptr(dev))))
     return out
+
+
+def maxsim_indexed_batch(q_packed, q_offsets, store, starts, lens, cand_offsets, mode: str = "maxsim"):
+    """Stage-2 scores for SEVERAL queries in one launch: query j has tokens
+    q_packed[q_offsets[j]:q_offsets[j+1]] and candidates starts/lens[cand_offsets[j]:cand_offsets[j+1]]
+    (rows of the resident token ``store``).  q_offsets / cand_offsets: host int sequences of
+    nq+1 values starting at 0.  Returns float32 [cand_offsets[-1]] on the GPU."""
+    import numpy as np
+    torch = _torch()
+    lib = _lib.load()
+    if q_packed.dtype != store.dtype:
+        q_packed = q_packed.to(store.dtype)
+    q_packed = q_packed.contiguous()
+    if not store.is_contiguous():
+        raise ValueError("token store must be contiguous")
+    qo = np.ascontiguousarray(np.asarray(q_offsets, dtype=np.int32))
+    co = np.ascontiguousarray(np.asarray(cand_offsets, dtype=np.int32))
+    if qo.ndim != 1 or qo.shape != co.shape or qo.size < 1 or qo[0] != 0 or co[0] != 0:
+        raise ValueError("q_offsets / cand_offsets must be 1-D, of equal length nq+1, starting at 0")
+    nq = qo.size - 1
+    if int(qo[-1]) != q_packed.shape[0]:
+        raise ValueError("q_offsets[-1] must equal the number of packed query tokens")
+    starts = starts.to(device=q_packed.device, dtype=torch.int64).contiguous()
+    lens = lens.to(device=q_packed.device, dtype=torch.int32).contiguous()
+    n = int(co[-1])
+    if starts.numel() != n or lens.numel() != n:
+        raise ValueError("starts / lens must hold cand_offsets[-1] entries")
+    out = torch.empty((n,), dtype=torch.float32, device=q_packed.device)
+    if n == 0 or nq == 0:
+        return out
+    dev = q_packed.device.index
+    _lib.check(lib.ts_maxsim_indexed_batch(ctypes.c_void_p(q_packed.data_ptr()), qo.ctypes.data_as(ctypes.c_void_p), nq,
+                                           ctypes.c_void_p(store.data_ptr()), ctypes.c_void_p(starts.data_ptr()),
+                                           ctypes.c_void_p(lens.data_ptr()), co.ctypes.data_as(ctypes.c_void_p),
+                                           q_packed.shape[1], _tensor_dtype(q_packed), 0 if mode == "maxsim" else 1,
+                                           ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+    return out

@@ -249,19 +249,48 @@ class RetrievalPipeline:
         return [self.search(q, top_k) for q in queries]
 
     def search_many(self, queries: List[str], top_k: Optional[int] = None) -> List[Dict[str, Any]]:
-        """Same results as batch_search; stage 1 runs once for the whole batch (one
-        encoder pass, one sweep of the corpus for up to 64 queries at a time)."""
+        """Same result records as batch_search, every stage batched over the queries: one
+        bi-encoder pass and one sweep of the corpus per 64 queries (stage 1), one query forward
+        and one MaxSim launch (stage 2, with the resident token store), one length-sorted pass
+        of the cross-encoder over all (query, candidate) pairs (stage 3).  Stage times are
+        reported as equal shares of the batch's stage times."""
         if not self.stage1 or not self.stage2 or not self.stage3:
             self.initialize_stages()
         top_k = top_k or self.config.stage3_top_k
         if not queries:
             return []
-        t0 = self._now()
-        per_query = self.stage1.search_many(queries, self.config.stage1_top_k)
-        share = (time.time() - t0) / len(queries) if t0 else None
+        queries = list(queries)
+        n = len(queries)
+        total_start = self._now()
+        t = self._now()
+        s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
+        t1 = (time.time() - t) / n if t else None
+        t = self._now()
+        s2 = self.stage2.rescore_many(queries, s1)
+        t2 = (time.time() - t) / n if t else None
+        t = self._now()
+        s3 = self.stage3.rerank_many(queries, s2)
+        t3 = (time.time() - t) / n if t else None
+        total = (time.time() - total_start) / n if total_start else None
+        keep = self.config.save_intermediate_results
         out = []
-        for q, s1 in zip(queries, per_query):
-            out.append(self._run_later_stages(q, top_k, s1, self._now(), share))
+        for q, r1, r2, r3 in zip(queries, s1, s2, s3):
+            if not r1 or not r2:   # the reference's early returns (:363-371, :380-388)
+                out.append({"query": q, "results": [], "stage1_results": r1 if r1 else [], "stage2_results": [],
+                            "timing": ({"stage1_time": t1 or 0.0, "stage2_time": (t2 or 0.0) if r1 else 0.0,
+                                        "stage3_time": 0.0, "total_time": total or 0.0}
+                                       if self.config.enable_timing else {}),
+                            "performance_stats": self.performance_stats})
+                continue
+            if self.config.enable_timing:
+                self._update_performance_stats(t1, t2, t3, total)
+            out.append({"query": q, "results": r3[:top_k],
+                        "stage1_results": r1 if keep else [], "stage2_results": r2 if keep else [],
+                        "timing": ({"stage1_time": t1 or 0.0, "stage2_time": t2 or 0.0, "stage3_time": t3 or 0.0,
+                                    "total_time": total or 0.0} if self.config.enable_timing else {}),
+                        "performance_stats": self.performance_stats.copy()})
+        if self.config.auto_cleanup:
+            self._cleanup_memory()
         return out
 
     # -- persistence -------------------------------------------------------------

@@ -91,7 +91,8 @@ class ColBERTScorer:
     """ColBERT-style MaxSim scoring for multi-vector retrieval."""
 
     def __init__(self, config: Stage2Config, model: Any = None, tokenizer: Any = None,
-                 maxsim_fn: Optional[Callable] = None, maxsim_indexed_fn: Optional[Callable] = None):
+                 maxsim_fn: Optional[Callable] = None, maxsim_indexed_fn: Optional[Callable] = None,
+                 maxsim_indexed_batch_fn: Optional[Callable] = None):
         self.config = config
         self.logger = logging.getLogger(__name__)
         self.model = model
@@ -99,6 +100,7 @@ class ColBERTScorer:
         self.device = self._get_device()
         self._maxsim_fn = maxsim_fn
         self._maxsim_indexed_fn = maxsim_indexed_fn
+        self._maxsim_indexed_batch_fn = maxsim_indexed_batch_fn
         self._doc_cache: Dict[str, torch.Tensor] = {}
         self.token_store = TokenStore()        # filled by index_documents()
         self._store_slot: Dict[int, int] = {}  # pipeline doc_id -> slot in the store
@@ -268,6 +270,65 @@ class ColBERTScorer:
             doc_embeddings_list = self.encode_documents_batch(documents)
             scores = self.score_all(query_embeddings, doc_embeddings_list)
         return scores
+
+    def encode_queries_batch(self, queries: List[str]) -> List[torch.Tensor]:
+        """Token matrices [Lq_j, H] of several queries from ONE padded forward (the reference
+        encodes one query per call, :203-205; same values up to batch-padding noise)."""
+        out: List[torch.Tensor] = []
+        bs = max(self.config.batch_size, 1)
+        for s in range(0, len(queries), bs):
+            enc = self._tokenize_batch(list(queries[s:s + bs]))
+            hidden = self._forward(enc)
+            lens = enc["attention_mask"].sum(dim=1).tolist()
+            out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))
+        return out
+
+    def score_candidates_many(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]) -> List[List[float]]:
+        """stage-2 scores for several queries: one query forward for all of them and, when every
+        candidate lives in the token store, ONE MaxSim launch (ts_maxsim_indexed_batch)."""
+        if not queries:
+            return []
+        slots_list = None
+        if len(self.token_store):
+            slots_list = [[self._store_slot.get(c.get("doc_id"), -1) for c in cands] for cands in candidates_list]
+            if any(sl and min(sl) < 0 for sl in slots_list):
+                slots_list = None
+        if slots_list is None:   # no resident store (or a stranger among the candidates): query by query
+            return [self.score_candidates(q, c) if c else [] for q, c in zip(queries, candidates_list)]
+        q_embs = self.encode_queries_batch(list(queries))
+        store = self.token_store
+        starts_all, lens_all = store.device_tables()
+        dt = store.data.dtype
+        q_off, c_off = [0], [0]
+        for e, sl in zip(q_embs, slots_list):
+            q_off.append(q_off[-1] + int(e.shape[0]))
+            c_off.append(c_off[-1] + len(sl))
+        if c_off[-1] == 0:
+            return [[] for _ in queries]
+        q_packed = torch.cat([e.to(dt) for e in q_embs], 0).contiguous()
+        sel = torch.tensor([x for sl in slots_list for x in sl], dtype=torch.int64, device=starts_all.device)
+        fn = self._maxsim_indexed_batch_fn
+        if fn is None:
+            from .index import maxsim_indexed_batch  # HIP kernel; raises without the library or a GPU
+            fn = maxsim_indexed_batch
+        flat = fn(q_packed, q_off, store.data, starts_all[sel], lens_all[sel], c_off,
+                  self.config.scoring_method).detach().cpu().tolist()
+        return [[float(x) for x in flat[a:b]] for a, b in zip(c_off[:-1], c_off[1:])]
+
+    def _keep_top(self, candidates: List[Dict[str, Any]], scores: List[float]) -> List[Dict[str, Any]]:
+        scored = []
+        for cand, s in zip(candidates, scores):
+            u = cand.copy()
+            u["stage2_score"] = s
+            u["stage"] = "stage2"
+            scored.append(u)
+        scored.sort(key=lambda x: x["stage2_score"], reverse=True)  # stable, like the reference
+        return scored[: self.config.top_k_candidates]
+
+    def rescore_many(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]) -> List[List[Dict[str, Any]]]:
+        """rescore_candidates for several queries at once (same records per query)."""
+        scores = self.score_candidates_many(queries, candidates_list)
+        return [self._keep_top(c, s) if c else [] for c, s in zip(candidates_list, scores)]
 
     def rescore_candidates(self, query: str, candidates: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
         if not candidates:

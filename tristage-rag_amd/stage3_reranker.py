@@ -32,6 +32,8 @@ class Stage3Config:
     use_gpu_if_available: bool = True
     activation_fxn: str = "sigmoid"  # "sigmoid" or "softmax" (HF path)
     normalize_scores: bool = True
+    # additive
+    many_batch_size: int = 256   # pairs per forward when several queries are reranked together (rerank_many)
 
 
 class CrossEncoderReranker:
@@ -134,6 +136,43 @@ class CrossEncoderReranker:
         final = reranked[: self.config.top_k_final]
         self.logger.info(f"Stage 3 reranking completed. Top score: {final[0]['stage3_score'] if final else 0:.4f}")
         return final
+
+    def rerank_many(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]) -> List[List[Dict[str, Any]]]:
+        """rerank() for several queries with ONE pass of the cross-encoder over all their pairs
+        (length-sorted, large batches); min-max, stable sort and top_k_final stay per query."""
+        if len(queries) != len(candidates_list):
+            raise ValueError("Number of queries must match number of candidate lists")
+        pairs: List[Tuple[str, str]] = []
+        bounds = [0]
+        for q, cands in zip(queries, candidates_list):
+            pairs.extend(self._prepare_input_pairs(q, [c["document"] for c in cands]))
+            bounds.append(len(pairs))
+        if not pairs:
+            return [[] for _ in queries]
+        original = self.config.batch_size
+        self.config.batch_size = max(original, self.config.many_batch_size)
+        try:
+            raw = (self._predict_with_sentence_transformers(pairs) if self.use_sentence_transformers
+                   else self._predict_with_huggingface(pairs))
+        finally:
+            self.config.batch_size = original
+        out = []
+        for cands, a, b in zip(candidates_list, bounds[:-1], bounds[1:]):
+            if not cands:
+                out.append([])
+                continue
+            scores = raw[a:b]
+            if self.config.normalize_scores:
+                scores = self._normalize_scores(scores)
+            reranked = []
+            for cand, s in zip(cands, scores):
+                u = cand.copy()
+                u["stage3_score"] = s
+                u["stage"] = "stage3"
+                reranked.append(u)
+            reranked.sort(key=lambda x: x["stage3_score"], reverse=True)
+            out.append(reranked[: self.config.top_k_final])
+        return out
 
     def batch_rerank(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]):
         if not queries or not candidates_list:
