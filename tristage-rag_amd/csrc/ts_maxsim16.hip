@@ -429,7 +429,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     for (int i = 0; i < M16_RING; ++i) {  // tail: refill from the next tile
       const u32x4 a = m16_use<FULL>(ring[i], g0 + i, h, H);
       M16_STEP(a, g0 + i);
-      if ((i + 1) % M16_GROUP == 0) {  // (nxt = cur after the slice's last tile: harmless re-read)
+      if ((i + 1) % M16_GROUP == 0 && has_next) {  // (wave-uniform: nothing is read past the slice)
 #pragma unroll
         for (int j = i + 1 - M16_GROUP; j <= i; ++j) ring[j] = m16_load<FULL>(nxt, j, h, H);
       }
