@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--store", action="store_true",
                     help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
     ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
+    ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of the timed region (stderr)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
     args = ap.parse_args()
@@ -59,6 +60,11 @@ def main():
     if args.many:
         p.search_many(queries[: args.many])   # warm-up of the batched shapes
         torch.cuda.synchronize()
+    prof = None
+    if args.cprofile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     if args.many:
         outs = []
@@ -68,6 +74,10 @@ def main():
         outs = [p.search(q) for q in queries]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(28)
     tm = {k: float(np.mean([o["timing"][k] for o in outs])) for k in ("stage1_time", "stage2_time", "stage3_time", "total_time")}
     g1 = getattr(p.stage1.model, "_graphed", None)
     g2 = getattr(p.stage2, "_graphed", None)

@@ -70,11 +70,19 @@ class HashTokenizer:
     def __init__(self, vocab_size: int = 30522, model_max_length: int = 512):
         self.vocab_size = int(vocab_size)
         self.model_max_length = int(model_max_length)
+        self._memo = {}
 
     def _ids(self, text: str) -> List[int]:
+        hit = self._memo.get(text)          # the same documents / queries recur across pairs and queries
+        if hit is not None:
+            return list(hit)
         pieces = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", text.lower())
         span = self.vocab_size - 1000
-        return [1000 + (zlib.crc32(p.encode("utf-8")) % span) for p in pieces]
+        ids = [1000 + (zlib.crc32(p.encode("utf-8")) % span) for p in pieces]
+        if len(self._memo) >= 100_000:
+            self._memo.clear()
+        self._memo[text] = tuple(ids)
+        return ids
 
     def __call__(self, text, text_pair=None, truncation=True, padding=False, max_length=None,
                  return_tensors=None, **_):
@@ -94,13 +102,19 @@ class HashTokenizer:
                 tt = [0] * len(ids)
             else:
                 b = self._ids(pairs[i])
-                if truncation:  # longest-first truncation, like HF's default strategy
-                    budget = max(max_length - 3, 0)
-                    while len(a) + len(b) > budget:
-                        if len(a) > len(b):
-                            a = a[:-1]
-                        else:
-                            b = b[:-1]
+                if truncation:  # longest-first truncation, like HF's default strategy: one token at a
+                    # time from the longer side, from the pair's second text on ties (closed form)
+                    la, lb = len(a), len(b)
+                    e = la + lb - max(max_length - 3, 0)
+                    if e > 0:
+                        if la > lb:
+                            c = min(e, la - lb)
+                            la, e = la - c, e - c
+                        elif lb > la:
+                            c = min(e, lb - la)
+                            lb, e = lb - c, e - c
+                        lb, la = lb - (e + 1) // 2, la - e // 2
+                        a, b = a[:max(la, 0)], b[:max(lb, 0)]
                 ids = [self.cls_token_id] + a + [self.sep_token_id] + b + [self.sep_token_id]
                 tt = [0] * (len(a) + 2) + [1] * (len(b) + 1)
             rows.append(ids)
