@@ -121,6 +121,17 @@ def _pipeline_worker(rank, world, port, out_dir):
                 assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (q, stage)
                 np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
             res.append([r["doc_id"] for r in a["results"]])
+        # batched: stage 1 collective, stages 2/3 split by query, one all-gather of the records
+        qs = ["neural network retrieval", "gpu memory d7", "zeta", "alpha beta index", "token d3"]
+        many, ref = par.search_many(qs), single.search_many(qs)
+        assert par.search_many([]) == []
+        for a, b in zip(many, ref):
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
+                np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+            res.append([r["doc_id"] for r in a["results"]])
+        again = par.search("gpu memory d7")            # the per-candidate collectives are back in place
+        assert [r["doc_id"] for r in again["results"]] == res[1]
         json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()

@@ -123,3 +123,44 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
 
         s2.score_candidates = score_candidates
         s3.raw_scores = raw_scores
+        self._local_scoring = (base2, base3)
+        self._parallel_scoring = (score_candidates, raw_scores)
+
+    def search_many(self, queries: List[str], top_k: Optional[int] = None) -> List[Dict[str, Any]]:
+        """Batched search over R ranks: stage 1 is collective (every rank sweeps its row shard
+        for all queries, one all-gather + merge per 64 queries); stages 2 and 3 are split BY
+        QUERY — rank r rescoring and reranking queries r, r+R, … with its replica of the
+        encoders and of the token store, no collective inside — and one all-gather of the
+        finished records puts every query's result on every rank."""
+        if self.world_size == 1:
+            return super().search_many(queries, top_k)
+        import time
+        if not self.stage1 or not self.stage2 or not self.stage3:
+            self.initialize_stages()
+        top_k = top_k or self.config.stage3_top_k
+        queries = list(queries)
+        if not queries:
+            return []
+        n, R, rank = len(queries), self.world_size, self.rank
+        total_start = self._now()
+        t = self._now()
+        s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
+        t1 = (time.time() - t) / n if t else None
+        mine = list(range(rank, n, R))
+        # the per-candidate collectives of search() must not run here: ranks work on different queries
+        self.stage2.score_candidates, self.stage3.raw_scores = self._local_scoring
+        try:
+            s2m, s3m, t2, t3 = self._later_stages_many([queries[i] for i in mine], [s1[i] for i in mine])
+        finally:
+            self.stage2.score_candidates, self.stage3.raw_scores = self._parallel_scoring
+        gathered: List[Any] = [None] * R
+        self._dist.all_gather_object(gathered, (s2m, s3m, t2, t3), group=self.group)
+        s2: List[Any] = [None] * n
+        s3: List[Any] = [None] * n
+        for r, (a, b, _, _) in enumerate(gathered):
+            for j, i in enumerate(range(r, n, R)):
+                s2[i], s3[i] = a[j], b[j]
+        t2 = max((g[2] or 0.0) for g in gathered) * len(mine) / n if t2 is not None else None
+        t3 = max((g[3] or 0.0) for g in gathered) * len(mine) / n if t3 is not None else None
+        total = (time.time() - total_start) / n if total_start else None
+        return self._assemble_many(queries, top_k, s1, s2, s3, t1, t2, t3, total)

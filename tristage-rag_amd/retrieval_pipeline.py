@@ -265,13 +265,22 @@ class RetrievalPipeline:
         t = self._now()
         s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
         t1 = (time.time() - t) / n if t else None
+        s2, s3, t2, t3 = self._later_stages_many(queries, s1)
+        total = (time.time() - total_start) / n if total_start else None
+        return self._assemble_many(queries, top_k, s1, s2, s3, t1, t2, t3, total)
+
+    def _later_stages_many(self, queries, s1):
+        """Stages 2 and 3 for several queries -> (stage-2 lists, stage-3 lists, per-query time shares)."""
+        n = max(len(queries), 1)
         t = self._now()
         s2 = self.stage2.rescore_many(queries, s1)
         t2 = (time.time() - t) / n if t else None
         t = self._now()
         s3 = self.stage3.rerank_many(queries, s2)
         t3 = (time.time() - t) / n if t else None
-        total = (time.time() - total_start) / n if total_start else None
+        return s2, s3, t2, t3
+
+    def _assemble_many(self, queries, top_k, s1, s2, s3, t1, t2, t3, total):
         keep = self.config.save_intermediate_results
         out = []
         for q, r1, r2, r3 in zip(queries, s1, s2, s3):
