@@ -323,6 +323,38 @@ def test_maxsim_indexed_reads_token_store_in_place(torch_mod, dtype):
                                atol=2e-6 if dtype == "f32" else 1e-5, rtol=0)
 
 
+def test_maxsim_more_candidates_than_one_launch_takes(torch_mod):
+    """> 4096 candidates: the streaming kernel is launched per chunk of 4096 (single query), and
+    the batched entry point falls back to per-query calls; tiny (0..4 token) candidates, so a
+    wave's slice crosses several candidates and empty ones sit between them."""
+    torch = torch_mod
+    from tristage_rag_amd.index import maxsim_indexed, maxsim_indexed_batch
+    rng = np.random.default_rng(77)
+    H, Lq, n = 64, 21, 9000
+    lens = rng.integers(0, 5, size=n)                      # 0..4 tokens: one (partial) tile each
+    store = oracle.quantize(rng.standard_normal((int(lens.sum()) + 4, H)).astype(np.float32), "bf16")
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    q = oracle.quantize(rng.standard_normal((Lq, H)).astype(np.float32), "bf16")
+    docs = [store[starts[i]: starts[i] + lens[i]] for i in range(n)]
+    want = oracle.maxsim_scores(q, docs)
+    tq, ts = torch.from_numpy(q).cuda().bfloat16(), torch.from_numpy(store).cuda().bfloat16()
+    t_s, t_l = torch.from_numpy(starts).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda()
+    got = maxsim_indexed(tq, ts, t_s, t_l).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=1e-5, rtol=0)
+    assert (got[lens == 0] == 0.0).all()
+    got2 = maxsim_indexed_batch(tq, [0, Lq], ts, t_s, t_l, [0, n]).cpu().numpy()
+    np.testing.assert_array_equal(got2, got)
+    # two queries x 4000 one-tile candidates in one launch
+    got3 = maxsim_indexed_batch(torch.cat([tq, tq]), [0, Lq, 2 * Lq], ts, torch.cat([t_s[:4000], t_s[:4000]]),
+                                torch.cat([t_l[:4000], t_l[:4000]]), [0, 4000, 8000]).cpu().numpy()
+    np.testing.assert_array_equal(got3[:4000], got[:4000])
+    np.testing.assert_array_equal(got3[4000:], got[:4000])
+    with pytest.raises(ValueError):
+        maxsim_indexed_batch(tq, [0, Lq], ts, t_s, t_l, [0, n - 1])            # starts/lens vs offsets
+    with pytest.raises(ValueError):
+        maxsim_indexed_batch(tq, [1, Lq], ts, t_s, t_l, [0, n])                # offsets must start at 0
+
+
 @pytest.mark.parametrize("dtype,H,lqs", [("bf16", 768, (5, 32, 17, 1)), ("f16", 384, (70, 9, 33, 150)),
                                          ("bf16", 96, (12, 40)), ("f32", 64, (7, 20))])
 def test_maxsim_batch_of_queries_in_one_launch(torch_mod, dtype, H, lqs):
