@@ -103,9 +103,6 @@ __device__ __forceinline__ int64_t m16_start_s(const Ms16Params& p, int d) {
 __device__ __forceinline__ int m16_len(const Ms16Params& p, int d) {
   return p.starts ? p.lens[d] : (p.doc_off[d + 1] - p.doc_off[d]);
 }
-__device__ __forceinline__ int64_t m16_start(const Ms16Params& p, int d) {
-  return p.starts ? p.starts[d] : (int64_t)p.doc_off[d];
-}
 // float -> uint whose unsigned order is the float order; 0 is below every finite value
 __device__ __forceinline__ uint32_t m16_key(float f) {
   const uint32_t b = __float_as_uint(f);
@@ -137,10 +134,6 @@ template <int DT> __device__ __forceinline__ float m16_sumsq(const u32x4& a, flo
     s = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, s, false);
   }
   return s;
-}
-template <int DT> __device__ __forceinline__ float m16_tofloat(uint16_t x) {
-  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, x);
-  else return __uint_as_float((uint32_t)x << 16);
 }
 template <int DT>
 __device__ __forceinline__ void m16_mma(f32x16& acc, const u32x4& a, const u32x4& b) {
