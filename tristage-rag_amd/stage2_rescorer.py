@@ -220,11 +220,15 @@ class ColBERTScorer:
         """Scores of every candidate with one kernel launch and one host copy."""
         if not doc_embeddings_list:
             return []
-        q = query_embeddings.squeeze(0).float().contiguous()
+        # 16-bit token matrices (bf16 autocast) stay 16-bit: half the bytes and the streaming kernel;
+        # the products are exact either way, so the scores are the ones the fp32 up-cast would give
+        dts = {d.dtype for d in doc_embeddings_list} | {query_embeddings.dtype}
+        dt = next(iter(dts)) if len(dts) == 1 and next(iter(dts)) in (torch.float16, torch.bfloat16) else torch.float32
+        q = query_embeddings.squeeze(0).to(dt).contiguous()
         lens = [int(d.shape[0]) for d in doc_embeddings_list]
         off = torch.zeros(len(lens) + 1, dtype=torch.int32)
         off[1:] = torch.cumsum(torch.tensor(lens, dtype=torch.int32), 0)
-        packed = torch.cat([d.reshape(-1, q.shape[1]) for d in doc_embeddings_list], 0).float().contiguous()
+        packed = torch.cat([d.reshape(-1, q.shape[1]) for d in doc_embeddings_list], 0).to(dt).contiguous()
         fn = self._maxsim_fn
         if fn is None:
             from .index import maxsim  # HIP kernel; raises without the library or a GPU
