@@ -420,3 +420,32 @@ def test_stage3_rerank_many_equals_per_query_rerank():
     assert rr.config.batch_size == 2
     with pytest.raises(ValueError):
         rr.rerank_many(["a"], [])
+
+
+def test_pipeline_persistence_restores_the_stage2_token_store(encoder, tmp_path):
+    """save_index / load_index (reference src/retrieval_pipeline.py:450-493) also carry the resident
+    stage-2 token store: from its safetensors file when it matches, re-encoded otherwise."""
+    def build(sub):
+        p = _pipeline(encoder, tmp_path / sub, stage1_enable_bm25=False, stage2_precompute_document_embeddings=True)
+        p.stage2._maxsim_indexed_fn, p.stage2._maxsim_indexed_batch_fn = oracle_maxsim_indexed, oracle_maxsim_indexed_batch
+        p.stage2.config.precompute_document_embeddings = True
+        return p
+    a = build("a")
+    a.add_documents(DOCS)
+    want = a.search("neural networks attention")
+    path = str(tmp_path / "idx" / "pipeline_index.pkl")
+    a.save_index(path)
+    assert os.path.exists(str(tmp_path / "idx" / "pipeline_index.stage2_tokens.safetensors"))
+    b = build("b")
+    b.load_index(path)
+    assert len(b.stage2.token_store) == len(DOCS) and b.stage2.token_store.lens == a.stage2.token_store.lens
+    assert torch.equal(b.stage2.token_store.data[: b.stage2.token_store.rows].cpu(),
+                       a.stage2.token_store.data[: a.stage2.token_store.rows].cpu())
+    got = b.search("neural networks attention")
+    assert [(r["doc_id"], r["stage2_score"]) for r in got["results"]] == [(r["doc_id"], r["stage2_score"]) for r in want["results"]]
+    os.remove(str(tmp_path / "idx" / "pipeline_index.stage2_tokens.safetensors"))
+    c = build("c")
+    c.load_index(path)                                   # no file: the store is re-encoded
+    assert len(c.stage2.token_store) == len(DOCS)
+    got = c.search("neural networks attention")
+    assert [r["doc_id"] for r in got["results"]] == [r["doc_id"] for r in want["results"]]

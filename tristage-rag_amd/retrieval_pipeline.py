@@ -309,7 +309,13 @@ class RetrievalPipeline:
         if index_path is None:
             index_path = os.path.join(self.config.index_dir, "pipeline_index.pkl")
         self.stage1.save_index(index_path)
+        if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
+            self.stage2.save_token_store(self._token_store_path(index_path))
         self.logger.info(f"Pipeline index saved to {index_path}")
+
+    @staticmethod
+    def _token_store_path(index_path: str) -> str:
+        return os.path.splitext(index_path)[0] + ".stage2_tokens.safetensors"
 
     def load_index(self, index_path: Optional[str] = None):
         if not self.stage1:
@@ -317,6 +323,12 @@ class RetrievalPipeline:
         if index_path is None:
             index_path = os.path.join(self.config.index_dir, "pipeline_index.pkl")
         self.stage1.load_index(index_path)
+        if self.stage2 is not None and self.stage2.config.precompute_document_embeddings and self.stage1.documents:
+            # the resident stage-2 token store comes back from its file, or is re-encoded
+            if not self.stage2.load_token_store(self._token_store_path(index_path), len(self.stage1.documents)):
+                from .stage2_rescorer import TokenStore
+                self.stage2.token_store, self.stage2._store_slot = TokenStore(), {}
+                self.stage2.index_documents(list(self.stage1.documents), 0)
         self.logger.info(f"Pipeline index loaded from {index_path}")
 
     # -- introspection -----------------------------------------------------------

@@ -248,6 +248,46 @@ class ColBERTScorer:
             for j in range(len(chunk)):
                 self._store_slot[first_doc_id + s + j] = base + j
 
+    # -- persistence of the token store (additive; the reference has nothing to persist for stage 2)
+    def save_token_store(self, path: str) -> bool:
+        """Token matrices + (start, length, doc id) tables as one safetensors file (data only)."""
+        if not len(self.token_store):
+            return False
+        from safetensors.torch import save_file
+        st = self.token_store
+        ids = sorted(self._store_slot, key=self._store_slot.get)
+        save_file({"tokens": st.data[: st.rows].contiguous().cpu(),
+                   "starts": torch.tensor(st.starts, dtype=torch.int64),
+                   "lens": torch.tensor(st.lens, dtype=torch.int32),
+                   "doc_ids": torch.tensor(ids, dtype=torch.int64)}, path,
+                  metadata={"format": "tristage-rag_amd/token-store/1", "model": str(self.config.model_name),
+                            "max_seq_length": str(self.config.max_seq_length)})
+        return True
+
+    def load_token_store(self, path: str, expected_docs: Optional[int] = None) -> bool:
+        """Restore what save_token_store wrote.  False (store left empty) when the file is absent,
+        was produced by another model / sequence length, or does not cover `expected_docs`."""
+        import os
+        if not os.path.exists(path):
+            return False
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata() or {}
+            if (meta.get("format") != "tristage-rag_amd/token-store/1" or meta.get("model") != str(self.config.model_name)
+                    or meta.get("max_seq_length") != str(self.config.max_seq_length)):
+                return False
+            lens = f.get_tensor("lens")
+            if expected_docs is not None and int(lens.numel()) != int(expected_docs):
+                return False
+            tokens, starts, ids = f.get_tensor("tokens"), f.get_tensor("starts"), f.get_tensor("doc_ids")
+        st = TokenStore()
+        st.data = tokens.to(self.device)
+        st.rows = int(tokens.shape[0])
+        st.starts, st.lens = [int(x) for x in starts.tolist()], [int(x) for x in lens.tolist()]
+        self.token_store = st
+        self._store_slot = {int(d): j for j, d in enumerate(ids.tolist())}
+        return True
+
     def _score_from_store(self, query_embeddings: torch.Tensor, candidates: List[Dict[str, Any]]):
         """Scores straight from the resident token store, or None if a candidate is not in it."""
         if not len(self.token_store):
