@@ -172,7 +172,8 @@ int ts_maxsim_indexed(const void* q, int32_t Lq, const void* store, const int64_
 /* The same for several queries in ONE launch (the batched caller: RetrievalPipeline.search_many):
  * query j has tokens [q_off[j], q_off[j+1]) of q [sum Lq, H] and candidates
  * [cand_off[j], cand_off[j+1]) of starts / lens / out.  q_off and cand_off are HOST arrays of
- * nq+1 int32 starting at 0; everything else is device memory.  A single query's launch is
+ * nq+1 int32 starting at 0 (they travel inside the kernel arguments, 64 queries per launch, so the
+ * caller may free them on return); everything else is device memory.  A single query's launch is
  * dominated by fixed costs (~25 of ~50 us at 1000 candidates); batched, they overlap with the
  * other queries' streaming.                                                              */
 int ts_maxsim_indexed_batch(const void* q, const int32_t* q_off, int32_t nq, const void* store,

@@ -349,6 +349,17 @@ def test_maxsim_more_candidates_than_one_launch_takes(torch_mod):
                                 torch.cat([t_l[:4000], t_l[:4000]]), [0, 4000, 8000]).cpu().numpy()
     np.testing.assert_array_equal(got3[:4000], got[:4000])
     np.testing.assert_array_equal(got3[4000:], got[:4000])
+    # 150 queries (more than one launch's 64), 3..20 candidates each
+    nq = 150
+    lq = rng.integers(1, 40, size=nq)
+    nc = rng.integers(3, 21, size=nq)
+    qq = oracle.quantize(rng.standard_normal((int(lq.sum()), H)).astype(np.float32), "bf16")
+    qo, co = np.concatenate([[0], np.cumsum(lq)]), np.concatenate([[0], np.cumsum(nc)])
+    pk = rng.integers(0, n, size=int(nc.sum()))
+    got4 = maxsim_indexed_batch(torch.from_numpy(qq).cuda().bfloat16(), qo, ts, t_s[pk], t_l[pk], co).cpu().numpy()
+    for j in (0, 63, 64, 65, 127, 128, 149):
+        dj = [docs[i] for i in pk[co[j]:co[j + 1]]]
+        np.testing.assert_allclose(got4[co[j]:co[j + 1]], oracle.maxsim_scores(qq[qo[j]:qo[j + 1]], dj), atol=1e-5, rtol=0)
     with pytest.raises(ValueError):
         maxsim_indexed_batch(tq, [0, Lq], ts, t_s, t_l, [0, n - 1])            # starts/lens vs offsets
     with pytest.raises(ValueError):

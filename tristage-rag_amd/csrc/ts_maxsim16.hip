@@ -58,6 +58,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define M16_NEG (-3.402823466e38f)
 
 #define M16_MAX_DOCS 4096   // candidates per launch (their tile prefix sums live in LDS)
+#define M16_MAX_BATCH 64    // queries per launch
 
 struct Ms16Params {
   const uint16_t* q;       // [Lq, H]
@@ -72,8 +73,11 @@ struct Ms16Params {
   int n_docs;              // <= M16_MAX_DOCS
   // several queries in one launch (blockIdx.z = query): query j owns query tokens
   // [q_off[j], q_off[j+1]) of q and candidates [cand_off[j], cand_off[j+1]) of starts/lens/out
-  const int32_t* q_off;    // device [nq+1] or null
-  const int32_t* cand_off; // device [nq+1]
+  // (offsets travel in the kernel arguments: captured at launch, no host->device copy whose
+  // source the caller could free too early)
+  int nq;                             // 0 = single query (q / Lq / n_docs above are final)
+  int32_t q_off[M16_MAX_BATCH + 1];
+  int32_t cand_off[M16_MAX_BATCH + 1];
   // scratch, all-zero between launches
   uint32_t* cnt;           // [n_docs] tiles (x passes) that have been folded into `best`
   uint32_t* best;          // [n_docs][lq_pad] ordered-uint keys of max_j cos(q_i, d_j); 0 = none
@@ -235,7 +239,7 @@ __device__ __forceinline__ void m16_flush_records(const Ms16Params& p, int nrec,
 template <int DT, int NQT, bool FULL>
 __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   Ms16Params p = pin;
-  if (pin.q_off) {  // one of several queries: narrow every array to this query's part
+  if (pin.nq) {  // one of several queries: narrow every array to this query's part
     const int qj = blockIdx.z;
     const int qa = pin.q_off[qj], ca = pin.cand_off[qj];
     p.Lq = pin.q_off[qj + 1] - qa;
@@ -489,10 +493,9 @@ std::mutex g_mu;
 std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
 int g_cus[64];
 
-// kind 0: the self-cleaning arrays (zero between launches); kind 1: plain temporary
-int scratch_get(int device, hipStream_t stream, size_t bytes, void** out, int kind = 0) {
+int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
   std::lock_guard<std::mutex> lk(g_mu);
-  Scratch& s = g_scratch[{device * 2 + kind, stream}];
+  Scratch& s = g_scratch[{device, stream}];
   if (s.bytes < bytes) {
     if (s.ptr) {
       TS_HIP(hipStreamSynchronize(stream));  // earlier launches may still use it
@@ -554,7 +557,7 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
 
   Ms16Params p;
   p.q = (const uint16_t*)q; p.Lq = Lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
-  p.docs = (const uint16_t*)docs; p.mode = mode; p.q_off = nullptr; p.cand_off = nullptr;
+  p.docs = (const uint16_t*)docs; p.mode = mode; p.nq = 0;
   const int chunk_max = M16_MAX_DOCS;
   const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
   void* ws = nullptr;
@@ -584,7 +587,8 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
 
 // Several queries, one launch (ts_maxsim_indexed_batch): the per-query fixed costs (launch,
 // query image, prefix sums, completion round trips: ~25 us of a ~50 us single-query launch)
-// overlap with other queries' streaming.  q_off / cand_off are HOST arrays.
+// overlap with other queries' streaming.  q_off / cand_off are HOST arrays; they reach the kernel
+// inside its arguments, 64 queries per launch.
 int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const void* store,
                              const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
                              int H, int dtype, int mode, float* out, int device, hipStream_t stream) {
@@ -622,30 +626,36 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
   if (const char* e = getenv("TS_M16_BATCH_GRID")) grid = atoi(e);
 #endif
 
-  void* ws = nullptr;
-  TS_CHECK(scratch_get(device, stream, (size_t)n_pairs * (1 + (size_t)lq_pad) * 4, &ws));
-  void* meta = nullptr;
-  const size_t mbytes = (size_t)(nq + 1) * 4;
-  TS_CHECK(scratch_get(device, stream, 2 * mbytes, &meta, 1));
-  TS_HIP(hipMemcpyAsync(meta, q_off, mbytes, hipMemcpyHostToDevice, stream));
-  TS_HIP(hipMemcpyAsync((char*)meta + mbytes, cand_off, mbytes, hipMemcpyHostToDevice, stream));
-
   Ms16Params p;
-  p.q = (const uint16_t*)q; p.Lq = max_lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
-  p.docs = (const uint16_t*)store; p.doc_off = nullptr; p.starts = starts; p.lens = lens;
-  p.n_docs = max_cand; p.mode = mode; p.out = out;
-  p.q_off = (const int32_t*)meta; p.cand_off = (const int32_t*)((char*)meta + mbytes);
-  p.cnt = (uint32_t*)ws;
-  p.best = p.cnt + n_pairs;
+  p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
+  p.docs = (const uint16_t*)store; p.doc_off = nullptr; p.mode = mode;
+  p.Lq = max_lq; p.n_docs = max_cand;
   const bool full = (H % (16 * M16_RING)) == 0;
+  for (int j0 = 0; j0 < nq; j0 += M16_MAX_BATCH) {   // (one launch unless > 64 queries)
+    const int nb = std::min(M16_MAX_BATCH, nq - j0);
+    const int qa = q_off[j0], ca = cand_off[j0];
+    const int64_t pairs = (int64_t)cand_off[j0 + nb] - ca;
+    if (pairs == 0) continue;
+    for (int j = 0; j <= nb; ++j) {
+      p.q_off[j] = q_off[j0 + j] - qa;
+      p.cand_off[j] = cand_off[j0 + j] - ca;
+    }
+    p.nq = nb;
+    p.q = (const uint16_t*)q + (size_t)qa * H;
+    p.starts = starts + ca; p.lens = lens + ca; p.out = out + ca;
+    void* ws = nullptr;
+    TS_CHECK(scratch_get(device, stream, (size_t)pairs * (1 + (size_t)lq_pad) * 4, &ws));
+    p.cnt = (uint32_t*)ws;
+    p.best = p.cnt + pairs;
 #define M16_GO(DT_, NQT_)                                                       \
-  (full ? launch_main<DT_, NQT_, true>(p, grid, lds, stream, nq)                \
-        : launch_main<DT_, NQT_, false>(p, grid, lds, stream, nq))
-  if (dtype == TS_F16) {
-    if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
-  } else {
-    if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
-  }
+  (full ? launch_main<DT_, NQT_, true>(p, grid, lds, stream, nb)                \
+        : launch_main<DT_, NQT_, false>(p, grid, lds, stream, nb))
+    if (dtype == TS_F16) {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
+    } else {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
+    }
 #undef M16_GO
+  }
   return TS_OK;
 }
