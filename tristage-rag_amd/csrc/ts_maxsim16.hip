@@ -107,6 +107,11 @@ __device__ __forceinline__ int64_t m16_start_s(const Ms16Params& p, int d) {
 __device__ __forceinline__ int m16_len(const Ms16Params& p, int d) {
   return p.starts ? p.lens[d] : (p.doc_off[d + 1] - p.doc_off[d]);
 }
+// tiles of a candidate of `len` token rows.  Capped (8 M tokens) so that the int32 sums over
+// <= 4096 candidates cannot overflow whatever a caller's `lens` array holds.
+__device__ __forceinline__ int m16_tiles(int len) {
+  return len > 0 ? min((len + 31) / 32, 1 << 18) : 0;
+}
 // float -> uint whose unsigned order is the float order; 0 is below every finite value
 __device__ __forceinline__ uint32_t m16_key(float f) {
   const uint32_t b = __float_as_uint(f);
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   int mytiles = 0;
   for (int d = d0; d < d1; ++d) {
     const int len = m16_len(p, d);
-    mytiles += len > 0 ? (len + 31) / 32 : 0;
+    mytiles += m16_tiles(len);
     if (len <= 0 && blockIdx.x == 0 && blockIdx.y == 0)
       p.out[d] = 0.f;  // reference: a candidate that cannot be scored keeps 0.0 (:285-291)
   }
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     for (int d = d0; d < d1; ++d) {
       prefix[d] = run;
       const int len = m16_len(p, d);  // (L1/L2 hit: read a moment ago)
-      run += len > 0 ? (len + 31) / 32 : 0;
+      run += m16_tiles(len);
     }
     if (tid == 0) prefix[p.n_docs] = T;
   }
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     const bool has_next = it + 1 < hi;
     int ndoc = doc, ntile = tile + 1, nlen = len;
     int64_t nstart = start;
-    if (has_next && ntile * 32 >= len) {
+    if (has_next && ntile >= m16_tiles(len)) {
       ntile = 0;
       ndoc = __builtin_amdgcn_readfirstlane(ndoc);
       do { ++ndoc; nlen = m16_len_s(p, ndoc); } while (nlen <= 0);  // a later tile exists: terminates
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       if (lane == nrec) {
         rdoc = doc;
         rtiles = run_tiles;
-        rneed = (uint32_t)p.passes * (uint32_t)((len + 31) / 32);
+        rneed = (uint32_t)p.passes * (uint32_t)m16_tiles(len);
       }
       run_tiles = 0;
       if (++nrec == 64) {  // (only with very many tiny candidates per wave)
