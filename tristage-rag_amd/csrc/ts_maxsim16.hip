@@ -18,7 +18,8 @@
 //     directly in MFMA A-fragment order (lane (r,h): 16 B of row r at byte 32g+16h):
 //     32 rows x 32 B per instruction.  Plain loads (NOT nt: each 128-byte line is
 //     touched by four consecutive instructions; with nt the line is refetched, measured
-//     3.3 vs 6.2 TB/s, tools/bw_probe.hip "rowfrag"), an 8-deep register ring per wave.
+//     3.3 vs 6.2 TB/s, tools/bw_probe.hip "rowfrag"), a 16-deep register ring per wave,
+//     refilled 8 slots at a time.
 //   * the query tokens (<= 64 per pass) are the stationary operand: staged once per
 //     workgroup into LDS in B-fragment order, lane-linear ds_read_b128.
 //   * v_mfma_f32_32x32x16_{f16,bf16}: accumulator column <-> query token (lane),
@@ -43,11 +44,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef M16_THREADS
-#define M16_THREADS 512
-#endif
+#define M16_THREADS 256  // 4 waves per workgroup, one workgroup per CU: fewer, fatter waves get more
+#endif                   // tiles each, so the last, partly filled round of tiles weighs less
+                         // (8 waves x 8 KiB: 51.6 us per 1000-candidate query, 4 x 16 KiB: 48.4)
 #define M16_WAVES (M16_THREADS / 64)
 #ifndef M16_RING
-#define M16_RING 8      // k steps (1 KiB each) kept in flight per wave
+#define M16_RING 16     // k steps (1 KiB each) in the register ring of a wave
 #endif
 #ifndef M16_GROUP
 #define M16_GROUP 8     // ring slots refilled together.  Issuing the loads that share a 128-byte line
@@ -229,6 +231,16 @@ __device__ __forceinline__ void m16_flush_records(const Ms16Params& p, int nrec,
   }
 }
 
+#if defined(TS_TUNING) && defined(M16_TRACE)  // diagnostic builds only: per-wave phase time stamps (100 MHz)
+__device__ unsigned long long m16_trace_buf[4096 * 8];
+#define M16_STAMP(i) do { if (lane == 0 && gwt < 4096) m16_trace_buf[gwt * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int ts_debug_m16_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(m16_trace_buf), sizeof(m16_trace_buf)) == hipSuccess ? 0 : -2;
+}
+#else
+#define M16_STAMP(i) do { } while (0)
+#endif
+
 // one k step: the row norms and NQT MFMAs on operand `a` of step g
 #if defined(TS_TUNING) && defined(M16_DBG_NOCOMPUTE)  // ablation builds only: loads kept live, no math
 #define M16_STEP(a, g) do { dsq += __uint_as_float(((a)[0] ^ (a)[1] ^ (a)[2] ^ (a)[3]) & 0x007fffffu); } while (0)
@@ -268,6 +280,10 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   const int q0 = blockIdx.y * (NQT * 32);  // first query token of this pass
   const int H = p.H;
   const int S = p.s_pad;
+#if defined(TS_TUNING) && defined(M16_TRACE)
+  const int gwt = (tid >> 6) * gridDim.x + blockIdx.x;
+#endif
+  M16_STAMP(0);
 
   // ---- tiles per candidate of this thread's share of the candidates (loads go out first)
   const int per = (p.n_docs + M16_THREADS - 1) / M16_THREADS;   // <= M16_MAX_DOCS / M16_THREADS
@@ -308,6 +324,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   // vmcnt(0) in front of the first reuse of their registers — inside the tile loop, where it
   // drains the ring once per tile.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+  M16_STAMP(1);
 
   // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + 8 wave totals)
   int incl = mytiles;
@@ -341,6 +358,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
   const int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
   const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
+  M16_STAMP(2);
   if (lo >= hi) return;  // (no block-level barrier below)
 
   int doc, tile, len;
@@ -365,6 +383,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
   }
 
+  M16_STAMP(3);
   const u32x4* ql = qlds + lane;
   // ---- 1/|q_i| of this lane's query token(s), from the image (fixed order: deterministic)
   float invq[NQT];
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     }
   }
 
+  M16_STAMP(4);
   float* myinv = invl + wave * 32;
   float best[NQT];
 #pragma unroll
@@ -458,6 +478,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     ++run_tiles;
+    if (it == lo) M16_STAMP(5);
 
     // ---- leaving this candidate (or the slice): publish the maxima, remember the candidate
     if (!has_next || ndoc != doc) {
@@ -481,7 +502,9 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     }
     doc = ndoc; tile = ntile; len = nlen; start = nstart; cur = nxt;
   }
+  M16_STAMP(6);
   if (nrec) m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane);
+  M16_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------
