@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 runs for profiles/: kernel trace + stats, then PMC passes (separate runs).
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r01d
+OUT=$R/gpurun_out/prof_r01e
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/trace_bench.log 2>&1
