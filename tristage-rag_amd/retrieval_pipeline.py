@@ -261,13 +261,22 @@ class RetrievalPipeline:
             return []
         queries = list(queries)
         n = len(queries)
-        total_start = self._now()
-        t = self._now()
-        s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
-        t1 = (time.time() - t) / n if t else None
-        s2, s3, t2, t3 = self._later_stages_many(queries, s1)
-        total = (time.time() - total_start) / n if total_start else None
-        return self._assemble_many(queries, top_k, s1, s2, s3, t1, t2, t3, total)
+        # a batch builds ~n x stage1_top_k candidate records; the cyclic collector would rescan
+        # them on every allocation burst (measured: a list comprehension over 6400 pairs took 69 ms)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            total_start = self._now()
+            t = self._now()
+            s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
+            t1 = (time.time() - t) / n if t else None
+            s2, s3, t2, t3 = self._later_stages_many(queries, s1)
+            total = (time.time() - total_start) / n if total_start else None
+            return self._assemble_many(queries, top_k, s1, s2, s3, t1, t2, t3, total)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def _later_stages_many(self, queries, s1):
         """Stages 2 and 3 for several queries -> (stage-2 lists, stage-3 lists, per-query time shares)."""
