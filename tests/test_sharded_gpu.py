@@ -77,3 +77,57 @@ def test_sharded_index_rccl_world_of_one():
             assert torch.equal(Ia, I if i % 2 == 0 else I2) and torch.equal(Da, D if i % 2 == 0 else D2), i
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from helpers import make_corpus as mk
+    from tristage_rag_amd.sharded import ShardedFlatIPIndex, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        n, d, k = 150_001, 128, 200                      # odd row count: unequal shards
+        corpus = mk(n, d, dtype="f16")
+        corpus[n // 2 + 7] = corpus[5]                   # the same row on both shards: a tie across ranks
+        lo, hi = shard_bounds(n, world, rank)
+        idx = ShardedFlatIPIndex(d, n, dtype="f16", device=0)
+        idx.add_local(torch.from_numpy(corpus[lo:hi]).cuda().half())
+        assert idx.local_index.ntotal == hi - lo
+        qs = [torch.from_numpy(mk(64, d, seed=40 + i, dtype="f16")).cuda().half() for i in range(3)]
+        sync = [idx.search(q, k) for q in qs]
+        torch.cuda.synchronize()
+        outs = [idx.search(qs[i % 3], k, async_=True, inputs_ready=True) for i in range(55)]   # > 48: finish() mid-way
+        idx.finish()
+        for i, (Da, Ia) in enumerate(outs):
+            assert torch.equal(Ia, sync[i % 3][1]) and torch.equal(Da, sync[i % 3][0]), i
+        np.save(os.path.join(out_dir, f"D{rank}.npy"), torch.stack([s[0] for s in sync]).cpu().numpy())
+        np.save(os.path.join(out_dir, f"I{rank}.npy"), torch.stack([s[1] for s in sync]).cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_full_protocol(tmp_path):
+    """Two PROCESSES (gloo group, exchange staged through the host) each owning a row shard on
+    the same GPU: the whole multi-rank protocol on the real kernels — global ids, pipelined
+    asynchronous searches, the collective finish(), the packed merge — equals the oracle and is
+    identical on both ranks."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    n, d, k = 150_001, 128, 200
+    corpus = make_corpus(n, d, dtype="f16")
+    corpus[n // 2 + 7] = corpus[5]
+    D0, I0 = np.load(tmp_path / "D0.npy"), np.load(tmp_path / "I0.npy")
+    assert np.array_equal(I0, np.load(tmp_path / "I1.npy")) and np.array_equal(D0, np.load(tmp_path / "D1.npy"))
+    for i in range(3):
+        q = make_corpus(64, d, seed=40 + i, dtype="f16")
+        check_topk(D0[i][:8], I0[i][:8], corpus, q[:8], k)

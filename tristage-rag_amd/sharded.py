@@ -120,6 +120,9 @@ class ShardedFlatIPIndex:
             self._pending.append((q, k, packed, out))
         return out
 
+    def _host_staged(self) -> bool:
+        return self._dist.is_initialized() and self._dist.get_backend(self.group) == "gloo"
+
     def _packed_buffer(self, B: int, k: int, device):
         import torch
         if (B * k) % 2:
@@ -130,8 +133,15 @@ class ShardedFlatIPIndex:
         """ONE collective (all-gather of the packed partial results) + the merge kernel,
         which reads the gathered buffer in place."""
         import torch
-        flat = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8, device=packed.device)
-        self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
+        if packed.is_cuda and self._host_staged():
+            # a gloo group (tests: several ranks sharing one GPU) cannot move device memory:
+            # the same exchange through host copies
+            host = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8)
+            self._dist.all_gather_into_tensor(host, packed.cpu(), group=self.group)
+            flat = host.to(packed.device)
+        else:
+            flat = torch.empty((self.world_size * packed.numel(),), dtype=torch.uint8, device=packed.device)
+            self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
         if self.merge_packed_fn is not None:
             return self.merge_packed_fn(flat, self.world_size, B, k)
         ns = 4 * B * k
@@ -156,7 +166,12 @@ class ShardedFlatIPIndex:
             pos = len(self._pending) - 1 - (last - t)
             if 0 <= pos < len(self._pending):
                 flags[pos] = 1
-        self._dist.all_reduce(flags, op=self._dist.ReduceOp.MAX, group=self.group)
+        if flags.is_cuda and self._host_staged():
+            hf = flags.cpu()
+            self._dist.all_reduce(hf, op=self._dist.ReduceOp.MAX, group=self.group)
+            flags = hf
+        else:
+            self._dist.all_reduce(flags, op=self._dist.ReduceOp.MAX, group=self.group)
         for pos in torch.nonzero(flags).flatten().tolist():
             q, k, packed, out = self._pending[pos]   # packed was corrected in place by local finish()
             Dn, In = self._exchange_and_merge(packed, q.shape[0], k)
