@@ -130,7 +130,7 @@ class HashTokenizer:
             mask = [[1] * len(r) for r in rows]
         out = {"input_ids": rows, "attention_mask": mask, "token_type_ids": types}
         if return_tensors == "pt":
-            out = {k: torch.tensor(v, dtype=torch.long) for k, v in out.items()}
+            out = {k: torch.from_numpy(np.asarray(v, dtype=np.int64)) for k, v in out.items()}
         return out
 
 
