@@ -33,7 +33,7 @@ class Stage3Config:
     activation_fxn: str = "sigmoid"  # "sigmoid" or "softmax" (HF path)
     normalize_scores: bool = True
     # additive
-    many_batch_size: int = 256   # pairs per forward when several queries are reranked together (rerank_many)
+    many_batch_size: int = 1024  # pairs per forward when several queries are reranked together (rerank_many)
 
 
 class CrossEncoderReranker:
