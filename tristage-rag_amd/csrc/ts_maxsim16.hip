@@ -55,7 +55,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define M16_GROUP 8     // ring slots refilled together.  Issuing the loads that share a 128-byte line
                         // set back to back matters: refilling one slot per step (GROUP 1) re-misses
                         // L1 for 3 of the 4 touches of a line: 4.35 TB/s vs 4.76 (GROUP 4) vs 5.09
-                        // (GROUP 8) on 600 MB of candidates (tools/diag_maxsim.sh)
+                        // (GROUP 8) on 600 MB of candidates (tools/variants_maxsim.sh)
 #endif
 #define M16_NEG (-3.402823466e38f)
 
