@@ -117,10 +117,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # TS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
+    # (ranks share devices, the exchange is staged through the host); never the measured setup
+    backend = os.environ.get("TS_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -194,7 +202,7 @@ def main():
     tm = local.timings(reset=True)
     info = local.last_search_info()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -238,7 +246,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"synthetic {args.rows}x{args.dim} {args.dtype} corpus, batch-{args.batch} "
                                     f"queries, stage-1 exact top-{args.k}, row-sharded over {world} GPU(s)"
-                                    + (", RCCL all-gather + HIP merge" if world > 1 else "")),
+                                    + ((", RCCL all-gather + HIP merge" if backend == "nccl" else
+                                        f", REHEARSAL: {backend} group, ranks share devices, host-staged exchange")
+                                       if world > 1 else "")),
                        "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
                        "submission": "synchronous per batch" if args.sync else
                                      ("batches enqueued back to back (async" + ("" if not pipeline else ", pipelined: prep/select of "
