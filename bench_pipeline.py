@@ -81,8 +81,10 @@ def main():
     tm = {k: float(np.mean([o["timing"][k] for o in outs])) for k in ("stage1_time", "stage2_time", "stage3_time", "total_time")}
     g1 = getattr(p.stage1.model, "_graphed", None)
     g2 = getattr(p.stage2, "_graphed", None)
+    g3 = getattr(p.stage3.model, "_graphed", None)
     graph_state = {"stage1": None if g1 is None else {"buckets": sorted(g1._graphs), "eager_fallback": g1._broken},
-                   "stage2": None if g2 is None else {"buckets": sorted(g2._graphs), "eager_fallback": g2._broken}}
+                   "stage2": None if g2 is None else {"buckets": sorted(g2._graphs), "eager_fallback": g2._broken},
+                   "stage3": None if g3 is None else {"buckets": sorted(g3._graphs), "eager_fallback": g3._broken}}
     print(json.dumps({
         "metric": "full 3-stage pipeline queries/sec (random-init models, throughput only)",
         "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,

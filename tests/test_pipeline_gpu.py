@@ -153,6 +153,17 @@ def test_hip_graph_query_forwards_match_eager(tmp_path):
         a, b = s_e.encode_query(t), s_g.encode_query(t)
         assert a.shape == b.shape
         assert torch.allclose(a, b, atol=1e-4)
+    # stage 3: one query's pairs as a single graph replay (rows and columns padded to a bucket)
+    from tristage_rag_amd.encoders import CrossEncoderModel
+    ce_e = CrossEncoderModel("random:tiny", device="cuda", use_amp=False)
+    ce_g = CrossEncoderModel("random:tiny", device="cuda", use_amp=False, use_hip_graph=True)
+    cdocs = _corpus(120)
+    for npairs in (1, 17, 100, 100, 120):
+        pairs = [["neural network attention", d] for d in cdocs[:npairs]]
+        np.testing.assert_allclose(ce_g.predict(pairs), ce_e.predict(pairs, batch_size=32), atol=1e-5)
+    assert ce_g._graphed is not None and not ce_g._graphed._broken and len(ce_g._graphed._graphs) >= 3
+    big = [["q", d] for d in (cdocs * 3)[:300]]              # more rows than the largest bucket: eager path
+    np.testing.assert_allclose(ce_g.predict(big), ce_e.predict(big), atol=1e-5)
     from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
     docs = _corpus(200)
     outs = []

@@ -272,6 +272,81 @@ class GraphedForward:
         return out[:, :n].clone()
 
 
+class GraphedClassifier:
+    """One query's (query, candidate) pairs through a sequence-classification model as ONE
+    replayed HIP graph: the pairs are padded to a (rows, length) bucket — extra rows are
+    copies of the pad row with a single attended position, extra columns are masked — so the
+    ~100-pair rerank of a query is one launch-free forward instead of several launch-bound
+    eager ones.  Falls back to the eager forward (and remembers) if capture fails."""
+
+    ROWS = (16, 32, 64, 128, 256)
+    COLS = (32, 64, 128, 192, 256, 384, 512)
+
+    def __init__(self, model, pad_token_id: int = 0, amp_dtype=None, use_token_types: bool = True):
+        self.model = model
+        self.pad = int(pad_token_id or 0)
+        self.amp_dtype = amp_dtype
+        self.use_token_types = use_token_types
+        self._graphs: Dict[Tuple[int, int], Any] = {}
+        self._broken = False
+
+    def _run(self, ids, mask, types):
+        kw = {"input_ids": ids, "attention_mask": mask}
+        if types is not None:
+            kw["token_type_ids"] = types
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):   # see GraphedForward._run
+            if self.amp_dtype is not None:
+                with torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False):
+                    return self.model(**kw).logits.float()
+            return self.model(**kw).logits.float()
+
+    def _capture(self, R: int, L: int, device):
+        ids = torch.full((R, L), self.pad, dtype=torch.long, device=device)
+        mask = torch.zeros((R, L), dtype=torch.long, device=device)
+        mask[:, 0] = 1
+        types = torch.zeros((R, L), dtype=torch.long, device=device) if self.use_token_types else None
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._run(ids, mask, types)
+        torch.cuda.current_stream(device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run(ids, mask, types)
+        return g, ids, mask, types, out
+
+    def __call__(self, enc: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
+        """enc: input_ids / attention_mask (/ token_type_ids) [P, n] on the GPU -> logits [P, labels]
+        (a copy), or None when the shape has no bucket (caller runs eagerly)."""
+        ids_in, mask_in = enc["input_ids"], enc["attention_mask"]
+        P, n = int(ids_in.shape[0]), int(ids_in.shape[1])
+        R = next((b for b in self.ROWS if b >= P), None)
+        L = next((b for b in self.COLS if b >= n), None)
+        if self._broken or R is None or L is None:
+            return None
+        key = (R, L)
+        if key not in self._graphs:
+            try:
+                self._graphs[key] = self._capture(R, L, ids_in.device)
+            except Exception:
+                self._broken = True
+                torch.cuda.synchronize()
+                return None
+        g, ids, mask, types, out = self._graphs[key]
+        ids.fill_(self.pad)
+        mask.zero_()
+        mask[:, 0] = 1
+        ids[:P, :n].copy_(ids_in)
+        mask[:P, :n].copy_(mask_in)
+        if types is not None:
+            types.zero_()
+            if "token_type_ids" in enc:
+                types[:P, :n].copy_(enc["token_type_ids"])
+        g.replay()
+        return out[:P].clone()
+
+
 # --------------------------------------------------------------------------- bi-encoder
 class SentenceEncoder:
     """Stand-in for sentence_transformers.SentenceTransformer (see module docstring)."""
@@ -386,8 +461,10 @@ class CrossEncoderModel:
 
     def __init__(self, model_name: str, device: str = "auto", max_length: int = 256,
                  cache_folder: str = "./models", amp_dtype=torch.bfloat16, use_amp: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, use_hip_graph: bool = False):
         self.device = resolve_device(device)
+        self.use_hip_graph = use_hip_graph
+        self._graphed: Optional[GraphedClassifier] = None
         self.tokenizer, self.model, _ = load_backbone(model_name, cache_folder, "seqcls", num_labels=1,
                                                       seed=seed)
         self.model.to(self.device).eval()
@@ -410,6 +487,19 @@ class CrossEncoderModel:
         if not pairs:
             return torch.zeros((0, self.num_labels), device=self.device)
         res = torch.empty((len(pairs), self.num_labels), dtype=torch.float32, device=self.device)
+        if self.use_hip_graph and str(self.device).startswith("cuda") and len(pairs) <= GraphedClassifier.ROWS[-1]:
+            # one query's pairs: a single forward replayed from a HIP graph
+            enc = self.tokenizer([p[0] for p in pairs], [p[1] for p in pairs], truncation=True, padding=True,
+                                 max_length=self.max_length, return_tensors="pt")
+            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            if self._graphed is None:
+                self._graphed = GraphedClassifier(self.model, getattr(self.tokenizer, "pad_token_id", 0) or 0,
+                                                  self.amp_dtype if self.use_amp else None,
+                                                  use_token_types="token_type_ids" in enc and
+                                                  hasattr(self.model.config, "type_vocab_size"))
+            lg = self._graphed(enc)
+            if lg is not None:
+                return lg.reshape(len(pairs), -1)
         for s in range(0, len(pairs), batch_size):
             idx = order[s:s + batch_size]
             enc = self.tokenizer([pairs[i][0] for i in idx], [pairs[i][1] for i in idx], truncation=True,

@@ -68,7 +68,7 @@ class PipelineConfig:
     stage1_bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM, HIP scoring; None = when a GPU is used
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
-    use_hip_graphs: bool = False             # batch-1 query forwards of stages 1/2 replayed from HIP graphs
+    use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
 
 
 # (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
@@ -167,7 +167,7 @@ class RetrievalPipeline:
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
                 max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
-                top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16))
+                top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs))
             self.logger.info("Stage 3 initialized")
         except Exception as e:
             self.logger.error(f"Error initializing pipeline stages: {e}")

@@ -33,6 +33,7 @@ class Stage3Config:
     activation_fxn: str = "sigmoid"  # "sigmoid" or "softmax" (HF path)
     normalize_scores: bool = True
     # additive
+    use_hip_graph: bool = False  # one query's pairs as a single forward replayed from a HIP graph
     many_batch_size: int = 1024  # pairs per forward when several queries are reranked together (rerank_many)
 
 
@@ -59,7 +60,8 @@ class CrossEncoderReranker:
             self.model = CrossEncoderModel(self.config.model_name, device=self.device,
                                            max_length=self.config.max_length,
                                            cache_folder=self.config.cache_dir,
-                                           use_amp=self.config.use_fp16)
+                                           use_amp=self.config.use_fp16,
+                                           use_hip_graph=self.config.use_hip_graph)
         # CrossEncoder-style object (predict on sentence pairs), like the reference's preferred path
         self.use_sentence_transformers = hasattr(self.model, "predict")
         if not self.use_sentence_transformers:
