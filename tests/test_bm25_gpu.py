@@ -48,6 +48,34 @@ def test_gpu_bm25_equals_host_bm25_on_a_larger_corpus():
     gpu.close()
 
 
+def test_gpu_bm25_prefilter_and_its_fallbacks():
+    """Long touched lists go through the sampled threshold + chip-wide filter before the exact
+    select; massive ties overflow the candidate list and must fall back to the exact select over
+    everything — results stay bit-identical to the host implementation either way."""
+    from tristage_rag_amd.stage1_retriever import BM25Index
+    rng = np.random.default_rng(11)
+    vocab = [f"w{i}" for i in range(300)]
+    p = 1.0 / np.arange(1, 301)
+    p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(5, 40)), p=p)) for _ in range(60_000)]
+    host, gpu = BM25Index(), BM25Index(gpu_device=0)
+    host.fit(docs)
+    gpu.fit(docs)
+    for q in ("w0 w1 w2 w3", "w0", "w5 w299", "w0 w0 w1 w200 w250"):      # w0 is in most documents
+        for k in (1, 10, 300, 2048):
+            a, b = host.search(q, k), gpu.search(q, k)
+            assert a == b, (q, k)
+    gpu.close()
+    same = ["alpha beta gamma"] * 30_000 + ["alpha delta"] * 10     # 30 000 exact ties at the top score... and below
+    host2, gpu2 = BM25Index(), BM25Index(gpu_device=0)
+    host2.fit(same)
+    gpu2.fit(same)
+    for q in ("alpha", "beta alpha", "delta"):
+        for k in (5, 300):
+            assert host2.search(q, k) == gpu2.search(q, k), (q, k)
+    gpu2.close()
+
+
 def test_stage1_with_gpu_bm25_equals_host_bm25(tmp_path):
     from tristage_rag_amd.encoders import SentenceEncoder
     from tristage_rag_amd.stage1_retriever import Stage1Config, Stage1Retriever

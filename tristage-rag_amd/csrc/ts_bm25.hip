@@ -14,12 +14,24 @@
 // MSB-first radix select (64 score bits, then 32 id bits) and a bitonic sort of
 // the k survivors.  Documents nobody touched score 0.0 and are filled in by the
 // host in ascending id order when fewer than k documents were touched.
+//
+// That select is one workgroup making up to 12 gathering passes over the touched list, which
+// is fine for thousands of documents and far too slow for millions (a common term touches a
+// large share of the corpus).  Above BM_PRE_MIN touched documents the list is first cut down
+// the way the stage-1 scan does it: score keys -> a strided sample -> the m-th best sample key
+// as threshold -> a chip-wide filter into a candidate list (~4k expected) -> the exact select on
+// the candidates.  The threshold only decides how fast: if the candidate list comes out short
+// or overflows (massive ties), the exact select runs over the whole touched list instead.
 #include "ts_common.h"
 
+#include <algorithm>
 #include <new>
 
 #define BM_SEL_THREADS 1024
 #define BM_MAX_K 2048
+#define BM_PRE_MIN 8192     // posting-list total below which the select runs on the touched list directly
+#define BM_SAMPLE 4096      // score keys sampled for the threshold
+#define BM_CAND_CAP 16384   // candidate list of the pre-filter
 
 struct ts_bm25 {
   int device = 0;
@@ -31,7 +43,10 @@ struct ts_bm25 {
   double* len_norm = nullptr;  // [N]  k1*(1-b+b*len/avg)
   double* acc = nullptr;       // [N], all zero between queries
   int32_t* touched = nullptr;  // [N]
-  uint32_t* counters = nullptr;  // [0] n_touched
+  uint32_t* counters = nullptr;  // [0] n_touched, [1] n_out, [2] n_cand, [3] 1 = candidates usable
+  uint64_t* keys = nullptr;    // [N] score keys of the touched documents (pre-filter)
+  int32_t* cand = nullptr;     // [BM_CAND_CAP]
+  uint64_t* tau = nullptr;     // [1]
   double* out_s = nullptr;     // [BM_MAX_K]
   int32_t* out_i = nullptr;    // [BM_MAX_K]
   int64_t* term_off = nullptr;  // host copy [V+1]
@@ -113,20 +128,85 @@ __device__ __forceinline__ bool key_ge(uint64_t sk, uint32_t dk, uint64_t tsk, u
   return sk > tsk || (sk == tsk && dk >= tdk);
 }
 
-// one workgroup: exact top-k of the touched documents
+// ---- pre-filter for long touched lists --------------------------------------------------
+__global__ void bm25_keys(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
+                          const double* __restrict__ acc, uint64_t* __restrict__ keys) {
+  const uint32_t n = *n_touched;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    keys[i] = d2key(acc[touched[i]]);
+}
+
+// one workgroup: tau = the m-th best of BM_SAMPLE strided keys, m ~ 4k * sample / n
+__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_tau(const uint64_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ n_touched, int k,
+                                                           uint64_t* __restrict__ tau,
+                                                           uint32_t* __restrict__ counters) {
+  __shared__ uint64_t sk[BM_SAMPLE];
+  const int tid = threadIdx.x;
+  const uint32_t n = *n_touched;
+  if (tid == 0) { counters[2] = 0; counters[3] = 0; }
+  if (n <= BM_PRE_MIN) {          // short list: the exact select takes it as it is
+    if (tid == 0) *tau = ~0ull;
+    return;
+  }
+  for (uint32_t j = tid; j < BM_SAMPLE; j += BM_SEL_THREADS)
+    sk[j] = keys[(uint64_t)j * n / BM_SAMPLE];
+  __syncthreads();
+  for (uint32_t size = 2; size <= BM_SAMPLE; size <<= 1) {   // bitonic, descending
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < BM_SAMPLE / 2; t += BM_SEL_THREADS) {
+        const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+        const bool desc = (i & size) == 0;
+        const uint64_t a = sk[i], b = sk[j];
+        if (desc ? (b > a) : (a > b)) { sk[i] = b; sk[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    uint64_t m = (4ull * (uint64_t)k * BM_SAMPLE + n - 1) / n;
+    if (m < 8) m = 8;
+    if (m > BM_SAMPLE) m = BM_SAMPLE;
+    *tau = sk[m - 1];
+    counters[3] = 1;
+  }
+}
+
+__global__ void bm25_filter(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
+                            const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tau,
+                            int32_t* __restrict__ cand, uint32_t* __restrict__ counters) {
+  if (counters[3] == 0) return;
+  const uint32_t n = *n_touched;
+  const uint64_t t = *tau;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (keys[i] >= t) {
+      const uint32_t pos = atomicAdd(&counters[2], 1u);
+      if (pos < BM_CAND_CAP) cand[pos] = touched[i];
+    }
+  }
+}
+
+// one workgroup: exact top-k of the documents in `touched` (the whole touched list, or the
+// candidate list of the pre-filter).  use_cand: 1 = run only if the candidate list is usable
+// (it holds at least min(k, n_touched) documents and did not overflow); 0 = run only if it is not.
 __global__ __launch_bounds__(BM_SEL_THREADS) void bm25_select(const int32_t* __restrict__ touched,
                                                               const uint32_t* __restrict__ n_touched,
                                                               const double* __restrict__ acc, int k,
                                                               double* __restrict__ out_s,
                                                               int32_t* __restrict__ out_i,
-                                                              uint32_t* __restrict__ n_out) {
+                                                              uint32_t* __restrict__ n_out,
+                                                              const uint32_t* __restrict__ counters,
+                                                              int use_cand) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[8];
   __shared__ uint64_t ssk[BM_MAX_K];
   __shared__ uint32_t sdk[BM_MAX_K];
   const int tid = threadIdx.x;
+  const uint32_t n_all = counters[0];
+  const uint32_t kk = (uint32_t)k < n_all ? (uint32_t)k : n_all;
+  const bool cand_ok = counters[3] != 0 && counters[2] >= kk && counters[2] <= BM_CAND_CAP;
+  if ((use_cand != 0) != cand_ok) return;   // (uniform) the other launch does the work
   const uint32_t n = *n_touched;
-  const uint32_t kk = (uint32_t)k < n ? (uint32_t)k : n;
   if (tid == 0) *n_out = kk;
   if (kk == 0) return;
   uint64_t psk = 0;
@@ -221,11 +301,13 @@ extern "C" int ts_bm25_create(int32_t device, ts_bm25** out) {
 }
 
 static void bm25_free(ts_bm25* h) {
-  void* bufs[] = {h->post_doc, h->post_tf, h->idf, h->len_norm, h->acc, h->touched, h->counters, h->out_s, h->out_i};
+  void* bufs[] = {h->post_doc, h->post_tf, h->idf, h->len_norm, h->acc, h->touched, h->counters, h->out_s, h->out_i,
+                  h->keys, h->cand, h->tau};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   h->post_doc = nullptr; h->post_tf = nullptr; h->idf = nullptr; h->len_norm = nullptr; h->acc = nullptr;
   h->touched = nullptr; h->counters = nullptr; h->out_s = nullptr; h->out_i = nullptr;
+  h->keys = nullptr; h->cand = nullptr; h->tau = nullptr;
   delete[] h->term_off; h->term_off = nullptr;
   delete[] h->idf_host; h->idf_host = nullptr;
 }
@@ -266,6 +348,9 @@ extern "C" int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, 
   TS_HIP(hipMalloc((void**)&h->counters, 64));
   TS_HIP(hipMalloc((void**)&h->out_s, BM_MAX_K * 8));
   TS_HIP(hipMalloc((void**)&h->out_i, BM_MAX_K * 4));
+  TS_HIP(hipMalloc((void**)&h->keys, n1 * 8));
+  TS_HIP(hipMalloc((void**)&h->cand, (size_t)BM_CAND_CAP * 4));
+  TS_HIP(hipMalloc((void**)&h->tau, 8));
   if (nnz) {
     TS_HIP(hipMemcpy(h->post_doc, post_doc, (size_t)nnz * 4, hipMemcpyHostToDevice));
     TS_HIP(hipMemcpy(h->post_tf, post_tf, (size_t)nnz * 4, hipMemcpyHostToDevice));
@@ -290,17 +375,30 @@ extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_ter
   if (h->N == 0 || n_terms == 0) return TS_OK;
   Guard g(h->device);
   hipStream_t s = (hipStream_t)stream;
+  int64_t total_df = 0;
   for (int i = 0; i < n_terms; ++i) {
     const int32_t t = term_ids[i];
     if (t < 0 || t >= h->V) { ts_set_error("term id %d out of range", t); return TS_ERR_INVALID; }
     const int64_t off = h->term_off[t], df = h->term_off[t + 1] - off;
     if (df <= 0) continue;
+    total_df += df;
     const int64_t blocks = (df + 255) / 256;
     hipLaunchKernelGGL(bm25_accumulate, dim3((unsigned)blocks), dim3(256), 0, s, h->post_doc, h->post_tf,
                        off, df, h->idf_host[t], h->k1p1, h->len_norm, h->acc, h->touched, h->counters);
   }
+  if (total_df > BM_PRE_MIN) {
+    // long touched list (its length is only known on the device; the postings' total bounds it)
+    const int blocks = (int)std::min<int64_t>(1024, (total_df + 255) / 256);
+    hipLaunchKernelGGL(bm25_keys, dim3(blocks), dim3(256), 0, s, h->touched, h->counters, h->acc, h->keys);
+    hipLaunchKernelGGL(bm25_tau, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->keys, h->counters, k, h->tau, h->counters);
+    hipLaunchKernelGGL(bm25_filter, dim3(blocks), dim3(256), 0, s, h->touched, h->counters, h->keys, h->tau,
+                       h->cand, h->counters);
+    hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->cand, h->counters + 2, h->acc, k,
+                       h->out_s, h->out_i, h->counters + 1, h->counters, 1);
+  }
+  // (runs only when the candidate list was not made or is not usable)
   hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->touched, h->counters, h->acc, k,
-                     h->out_s, h->out_i, h->counters + 1);
+                     h->out_s, h->out_i, h->counters + 1, h->counters, 0);
   TS_HIP(hipGetLastError());
   uint32_t cnt[2] = {0, 0};
   static thread_local int32_t ids32[BM_MAX_K];
@@ -308,7 +406,7 @@ extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_ter
   TS_HIP(hipMemcpyAsync(out_scores, h->out_s, (size_t)k * 8, hipMemcpyDeviceToHost, s));
   TS_HIP(hipMemcpyAsync(ids32, h->out_i, (size_t)k * 4, hipMemcpyDeviceToHost, s));
   hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
-  TS_HIP(hipMemsetAsync(h->counters, 0, 8, s));
+  TS_HIP(hipMemsetAsync(h->counters, 0, 16, s));
   TS_HIP(hipStreamSynchronize(s));
   const int32_t n = (int32_t)cnt[1];
   for (int32_t i = 0; i < n; ++i) out_ids[i] = ids32[i];
