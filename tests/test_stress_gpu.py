@@ -58,3 +58,58 @@ def test_long_pipelined_stream_is_deterministic():
             assert torch.equal(I, want[i % 8][1]) and torch.equal(D, want[i % 8][0]), (rep, i)
     check_topk(want[0][0].cpu().numpy()[:3], want[0][1].cpu().numpy()[:3], corpus, qs[0].float().cpu().numpy()[:3], 500)
     idx.close()
+
+
+def test_concurrent_host_threads():
+    """Several host threads at once (ctypes releases the GIL): two index handles searched
+    concurrently and the stateless MaxSim entry points sharing one stream's scratch buffer while
+    it grows.  Every result must equal its single-threaded value."""
+    import threading
+    import torch
+    from tristage_rag_amd.index import FlatIPIndex, maxsim_indexed
+    from helpers import make_corpus
+    rng = np.random.default_rng(3)
+    d = 128
+    idxs, qs, want = [], [], []
+    for t in range(2):
+        c = make_corpus(60_000 + 7 * t, d, seed=50 + t, dtype="f16")
+        idx = FlatIPIndex(d, dtype="f16")
+        idx.add(torch.from_numpy(c).cuda().half())
+        q = torch.from_numpy(make_corpus(64, d, seed=60 + t, dtype="f16")).cuda().half()
+        idxs.append(idx); qs.append(q); want.append(idx.search(q, 100))
+    H = 128
+    lens = rng.integers(1, 150, size=6000)
+    store = torch.from_numpy(rng.standard_normal((int(lens.sum()), H)).astype(np.float32)).cuda().bfloat16()
+    starts = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)[:-1]])).cuda()
+    tl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    q2 = torch.from_numpy(rng.standard_normal((20, H)).astype(np.float32)).cuda().bfloat16()
+    sizes = [50, 700, 3000, 6000]
+    ms_want = {n: maxsim_indexed(q2, store, starts[:n], tl[:n]) for n in sizes}
+    torch.cuda.synchronize()
+    errors = []
+
+    def search_worker(t):
+        try:
+            for _ in range(20):
+                D, I = idxs[t].search(qs[t], 100)
+                assert torch.equal(I, want[t][1]) and torch.equal(D, want[t][0])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def maxsim_worker(order):
+        try:
+            for _ in range(15):
+                for n in order:
+                    assert torch.equal(maxsim_indexed(q2, store, starts[:n], tl[:n]), ms_want[n])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=search_worker, args=(t,)) for t in range(2)]
+    threads += [threading.Thread(target=maxsim_worker, args=(o,)) for o in (sizes, sizes[::-1])]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for idx in idxs:
+        idx.close()

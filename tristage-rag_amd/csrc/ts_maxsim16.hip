@@ -521,8 +521,9 @@ std::mutex g_mu;
 std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
 int g_cus[64];
 
+// (callers hold g_mu from here until their launches are enqueued: another thread growing the
+// same stream's buffer must not free it between this call and the launch that uses it)
 int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
-  std::lock_guard<std::mutex> lk(g_mu);
   Scratch& s = g_scratch[{device, stream}];
   if (s.bytes < bytes) {
     if (s.ptr) {
@@ -588,6 +589,7 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
   p.docs = (const uint16_t*)docs; p.mode = mode; p.nq = 0;
   const int chunk_max = M16_MAX_DOCS;
   const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
+  std::lock_guard<std::mutex> lk(g_mu);
   void* ws = nullptr;
   TS_CHECK(scratch_get(device, stream, cells * 4, &ws));
   const bool full = (H % (16 * M16_RING)) == 0;  // no k step past H: unpredicated loads
@@ -659,6 +661,7 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
   p.docs = (const uint16_t*)store; p.doc_off = nullptr; p.mode = mode;
   p.Lq = max_lq; p.n_docs = max_cand;
   const bool full = (H % (16 * M16_RING)) == 0;
+  std::lock_guard<std::mutex> lk(g_mu);
   for (int j0 = 0; j0 < nq; j0 += M16_MAX_BATCH) {   // (one launch unless > 64 queries)
     const int nb = std::min(M16_MAX_BATCH, nq - j0);
     const int qa = q_off[j0], ca = cand_off[j0];
