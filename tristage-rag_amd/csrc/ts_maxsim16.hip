@@ -1,4 +1,5 @@
-// Stage-2 MaxSim for 16-bit token matrices on gfx950: the HBM-bound streaming form.
+// Stage-2 MaxSim on gfx950: the HBM-bound streaming form (f16 / bf16 token matrices, and f32
+// ones on the exact-f32 MFMA; rows are addressed in bytes, a k step is 32 bytes of a row).
 //
 // Same scores as ts_maxsim.hip (reference src/stage2_rescorer.py:167-201 applied to
 // every candidate, loop at :268-276):  for query tokens Q[Lq,H], document tokens D[Ld,H]
@@ -63,12 +64,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define M16_MAX_BATCH 64    // queries per launch
 
 struct Ms16Params {
-  const uint16_t* q;       // [Lq, H]
-  int Lq, H;
+  const unsigned char* q;  // [Lq, H] (row_bytes per row)
+  int Lq, H;               // H is carried as row_bytes = H * element size: a k step is 32 bytes of a row
+                           // (2 x 16-byte operand units) for every element type
   int s_pad;               // k steps per tile (16 elements each), multiple of M16_RING
   int lq_pad;              // row stride of `best` (= passes * NQT * 32)
   int passes;              // gridDim.y: query tokens are taken NQT*32 per pass
-  const uint16_t* docs;    // [rows, H] row-major
+  const unsigned char* docs;  // [rows, H] row-major
   const int32_t* doc_off;  // packed candidates: [n_docs+1] (or null)
   const int64_t* starts;   // token store: [n_docs]
   const int32_t* lens;     //              [n_docs]
@@ -126,8 +128,12 @@ __device__ __forceinline__ float m16_unkey(uint32_t k) {
 // sum of squares of the 8 values of one operand register quad.  (Whole-vector casts and
 // constant shuffles only: hipcc 7.2 miscompiles __builtin_bit_cast of a[i] inside an
 // unrolled loop — every iteration reads element 0; see DESIGN.md "Notes".)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int DT> __device__ __forceinline__ float m16_sumsq(const u32x4& a, float s) {
-  if constexpr (DT == TS_F16) {
+  if constexpr (DT == TS_F32) {
+    const f32x4v v = __builtin_bit_cast(f32x4v, a);
+    s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+  } else if constexpr (DT == TS_F16) {
     const h8 v = __builtin_bit_cast(h8, a);
     const h2 p0 = __builtin_shufflevector(v, v, 0, 1), p1 = __builtin_shufflevector(v, v, 2, 3);
     const h2 p2 = __builtin_shufflevector(v, v, 4, 5), p3 = __builtin_shufflevector(v, v, 6, 7);
@@ -148,7 +154,16 @@ template <int DT> __device__ __forceinline__ float m16_sumsq(const u32x4& a, flo
 }
 template <int DT>
 __device__ __forceinline__ void m16_mma(f32x16& acc, const u32x4& a, const u32x4& b) {
-  if constexpr (DT == TS_F16)
+  if constexpr (DT == TS_F32) {
+    // fp32 rows: the unit holds 4 consecutive floats; the t-th exact-f32 MFMA (K = 2: this
+    // lane's value and its h-partner's) contracts k = 8g + t and 8g + 4 + t — any pairing is
+    // fine as long as the query image uses the same one, which it does by construction
+    const f32x4v af = __builtin_bit_cast(f32x4v, a), bf = __builtin_bit_cast(f32x4v, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
+  } else if constexpr (DT == TS_F16)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), acc, 0, 0, 0);
   else
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
@@ -159,15 +174,15 @@ __device__ __forceinline__ void m16_mma(f32x16& acc, const u32x4& a, const u32x4
 // (a load under a lane predicate becomes a branch with s_waitcnt vmcnt(0) behind it, which
 // drains the ring): steps past H re-read unit 0 of the row and are zeroed when consumed.
 template <bool FULL>
-__device__ __forceinline__ u32x4 m16_load(const uint16_t* rowp, int g, int h, int H) {
-  if constexpr (FULL) return *reinterpret_cast<const u32x4*>(rowp + 16 * g);
-  const int off = (16 * g + 8 * h < H) ? 16 * g : 0;
+__device__ __forceinline__ u32x4 m16_load(const unsigned char* rowp, int g, int h, int row_bytes) {
+  if constexpr (FULL) return *reinterpret_cast<const u32x4*>(rowp + 32 * g);
+  const int off = (32 * g + 16 * h < row_bytes) ? 32 * g : 0;
   return *reinterpret_cast<const u32x4*>(rowp + off);
 }
 template <bool FULL>
-__device__ __forceinline__ u32x4 m16_use(const u32x4& v, int g, int h, int H) {
+__device__ __forceinline__ u32x4 m16_use(const u32x4& v, int g, int h, int row_bytes) {
   if constexpr (FULL) return v;
-  const bool ok = 16 * g + 8 * h < H;
+  const bool ok = 32 * g + 16 * h < row_bytes;
   return u32x4{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
 }
 
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     const int qa = pin.q_off[qj], ca = pin.cand_off[qj];
     p.Lq = pin.q_off[qj + 1] - qa;
     p.n_docs = pin.cand_off[qj + 1] - ca;
-    p.q = pin.q + (size_t)qa * pin.H;
+    p.q = pin.q + (size_t)qa * pin.H;   // (H = row bytes)
     p.starts += ca; p.lens += ca; p.out += ca;
     p.cnt += ca;
     p.best += (size_t)ca * pin.lq_pad;
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       for (int j = 0; j < 8; ++j) {
         const int u = u0 + j * M16_THREADS;
         const int l = u & 63, t = (u >> 6) % NQT, g = (u >> 6) / NQT;
-        const int qi = q0 + 32 * t + (l & 31), k = 16 * g + 8 * (l >> 5);
+        const int qi = q0 + 32 * t + (l & 31), k = 32 * g + 16 * (l >> 5);   // k: byte offset in the row
         const bool ok = u < units && qi < p.Lq && k < H;
         // always-issued load from a valid address, zeroed afterwards (no branch around the load)
         const u32x4 x = *reinterpret_cast<const u32x4*>(p.q + (ok ? (size_t)qi * H + k : 0));
@@ -374,11 +389,11 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     len = m16_len_s(p, doc);
     start = m16_start_s(p, doc);
   }
-  const uint16_t* cur;
+  const unsigned char* cur;
   u32x4 ring[M16_RING];
   {
     const int rows = min(32, len - tile * 32);
-    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 8 * h);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
 #pragma unroll
     for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
   }
@@ -421,10 +436,10 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       do { ++ndoc; nlen = m16_len_s(p, ndoc); } while (nlen <= 0);  // a later tile exists: terminates
       nstart = m16_start_s(p, ndoc);
     }
-    const uint16_t* nxt = cur;
+    const unsigned char* nxt = cur;
     if (has_next) {
       const int nrows = min(32, nlen - ntile * 32);
-      nxt = p.docs + ((size_t)(nstart + ntile * 32 + min(r, nrows - 1)) * H + 8 * h);
+      nxt = p.docs + ((size_t)(nstart + ntile * 32 + min(r, nrows - 1)) * H + 16 * h);
     }
 
     f32x16 acc[NQT];
@@ -560,10 +575,11 @@ static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s,
 int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* doc_off,
                        const int64_t* starts, const int32_t* lens, int n_docs, int H, int dtype,
                        int mode, float* out, int device, hipStream_t stream) {
-  if (dtype != TS_F16 && dtype != TS_BF16) return TS_ERR_UNSUPPORTED;
-  if (Lq <= 0 || n_docs <= 0 || (H % 8) != 0) return TS_ERR_UNSUPPORTED;
+  if (dtype != TS_F16 && dtype != TS_BF16 && dtype != TS_F32) return TS_ERR_UNSUPPORTED;
+  const int row_bytes = H * (dtype == TS_F32 ? 4 : 2);
+  if (Lq <= 0 || n_docs <= 0 || (row_bytes % 16) != 0) return TS_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(docs)) & 15) return TS_ERR_UNSUPPORTED;
-  const int s_real = (H + 15) / 16;
+  const int s_real = (row_bytes + 31) / 32;
   const int s_pad = ((s_real + M16_RING - 1) / M16_RING) * M16_RING;
   const size_t lds_cap = 156 * 1024;
   const size_t extra = M16_WAVES * 32 * sizeof(float) + 64 + ((size_t)M16_MAX_DOCS + 1) * 4 + 12;
@@ -585,14 +601,14 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
 #endif
 
   Ms16Params p;
-  p.q = (const uint16_t*)q; p.Lq = Lq; p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
-  p.docs = (const uint16_t*)docs; p.mode = mode; p.nq = 0;
+  p.q = (const unsigned char*)q; p.Lq = Lq; p.H = row_bytes; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
+  p.docs = (const unsigned char*)docs; p.mode = mode; p.nq = 0;
   const int chunk_max = M16_MAX_DOCS;
   const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
   std::lock_guard<std::mutex> lk(g_mu);
   void* ws = nullptr;
   TS_CHECK(scratch_get(device, stream, cells * 4, &ws));
-  const bool full = (H % (16 * M16_RING)) == 0;  // no k step past H: unpredicated loads
+  const bool full = (row_bytes % (32 * M16_RING)) == 0;  // no k step past the row: unpredicated loads
   for (int c0 = 0; c0 < n_docs; c0 += chunk_max) {   // (one launch unless > 4096 candidates)
     const int n = std::min(chunk_max, n_docs - c0);
     p.n_docs = n;
@@ -607,8 +623,10 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
         : launch_main<DT_, NQT_, false>(p, grid, lds, stream))
     if (dtype == TS_F16) {
       if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
-    } else {
+    } else if (dtype == TS_BF16) {
       if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
+    } else {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_F32, 2)); else TS_CHECK(M16_GO(TS_F32, 1));
     }
 #undef M16_GO
   }
@@ -622,8 +640,9 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
 int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const void* store,
                              const int64_t* starts, const int32_t* lens, const int32_t* cand_off,
                              int H, int dtype, int mode, float* out, int device, hipStream_t stream) {
-  if (dtype != TS_F16 && dtype != TS_BF16) return TS_ERR_UNSUPPORTED;
-  if (nq <= 0 || (H % 8) != 0) return TS_ERR_UNSUPPORTED;
+  if (dtype != TS_F16 && dtype != TS_BF16 && dtype != TS_F32) return TS_ERR_UNSUPPORTED;
+  const int row_bytes = H * (dtype == TS_F32 ? 4 : 2);
+  if (nq <= 0 || (row_bytes % 16) != 0) return TS_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(store)) & 15) return TS_ERR_UNSUPPORTED;
   int max_lq = 0, max_cand = 0;
   for (int j = 0; j < nq; ++j) {
@@ -635,7 +654,7 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
   const int64_t n_pairs = (int64_t)cand_off[nq] - cand_off[0];
   if (n_pairs <= 0) return TS_OK;
   if (q_off[0] != 0 || cand_off[0] != 0) return TS_ERR_UNSUPPORTED;
-  const int s_real = (H + 15) / 16;
+  const int s_real = (row_bytes + 31) / 32;
   const int s_pad = ((s_real + M16_RING - 1) / M16_RING) * M16_RING;
   const size_t lds_cap = 156 * 1024;
   const size_t extra = M16_WAVES * 32 * sizeof(float) + 64 + ((size_t)M16_MAX_DOCS + 1) * 4 + 12;
@@ -657,10 +676,10 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
 #endif
 
   Ms16Params p;
-  p.H = H; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
-  p.docs = (const uint16_t*)store; p.doc_off = nullptr; p.mode = mode;
+  p.H = row_bytes; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
+  p.docs = (const unsigned char*)store; p.doc_off = nullptr; p.mode = mode;
   p.Lq = max_lq; p.n_docs = max_cand;
-  const bool full = (H % (16 * M16_RING)) == 0;
+  const bool full = (row_bytes % (32 * M16_RING)) == 0;
   std::lock_guard<std::mutex> lk(g_mu);
   for (int j0 = 0; j0 < nq; j0 += M16_MAX_BATCH) {   // (one launch unless > 64 queries)
     const int nb = std::min(M16_MAX_BATCH, nq - j0);
@@ -672,7 +691,7 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
       p.cand_off[j] = cand_off[j0 + j] - ca;
     }
     p.nq = nb;
-    p.q = (const uint16_t*)q + (size_t)qa * H;
+    p.q = (const unsigned char*)q + (size_t)qa * row_bytes;
     p.starts = starts + ca; p.lens = lens + ca; p.out = out + ca;
     void* ws = nullptr;
     TS_CHECK(scratch_get(device, stream, (size_t)pairs * (1 + (size_t)lq_pad) * 4, &ws));
@@ -683,8 +702,10 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
         : launch_main<DT_, NQT_, false>(p, grid, lds, stream, nb))
     if (dtype == TS_F16) {
       if (nqt == 2) TS_CHECK(M16_GO(TS_F16, 2)); else TS_CHECK(M16_GO(TS_F16, 1));
-    } else {
+    } else if (dtype == TS_BF16) {
       if (nqt == 2) TS_CHECK(M16_GO(TS_BF16, 2)); else TS_CHECK(M16_GO(TS_BF16, 1));
+    } else {
+      if (nqt == 2) TS_CHECK(M16_GO(TS_F32, 2)); else TS_CHECK(M16_GO(TS_F32, 1));
     }
 #undef M16_GO
   }
