@@ -1,5 +1,6 @@
 // Stage-2 MaxSim on gfx950: the HBM-bound streaming form (f16 / bf16 token matrices, and f32
-// ones on the exact-f32 MFMA; rows are addressed in bytes, a k step is 32 bytes of a row).
+// ones on the exact-f32 MFMA; rows are addressed in bytes, a k step is 32 bytes of a row — the
+// "16" in the names is the 16-byte operand unit every lane loads).
 //
 // Same scores as ts_maxsim.hip (reference src/stage2_rescorer.py:167-201 applied to
 // every candidate, loop at :268-276):  for query tokens Q[Lq,H], document tokens D[Ld,H]
