@@ -312,7 +312,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       p.out[d] = 0.f;  // reference: a candidate that cannot be scored keeps 0.0 (:285-291)
   }
 
-  // ---- Q image: unit (g*NQT + t)*64 + l = Q[q0 + 32t + (l&31)][16g + 8(l>>5) .. +8]
+  // ---- Q image: unit (g*NQT + t)*64 + l = the 16 bytes at byte 32g + 16(l>>5) of query row q0 + 32t + (l&31)
   // (8 independent L2 reads in flight per thread: one at a time costs ~1 us each)
   {
     const int units = S * NQT * 64;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
   M16_STAMP(1);
 
-  // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + 8 wave totals)
+  // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + the waves' totals)
   int incl = mytiles;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
