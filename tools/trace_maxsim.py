@@ -22,12 +22,12 @@ for rep in range(4):
     out = maxsim_indexed(q, store, starts_all[pk].contiguous(), lens_all[pk].to(torch.int32).contiguous())
     torch.cuda.synchronize()
 assert lib.ts_debug_m16_trace(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)[:2048]
+t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)[:1024]
 act = t[:, 7] > 0
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
 names = ["entry", "q image staged", "prefix+barrier", "slice+ring issued", "q norms", "first tile", "slice done", "flushed"]
-print(f"docs={docs}: {int(act.sum())} active waves of 2048")
+print(f"docs={docs}: {int(act.sum())} active waves of 1024")
 for i, n in enumerate(names):
     col = us[act, i] if i >= 3 else us[:, i]
     print(f"  {i} {n:20s} min {col.min():7.2f}  median {np.median(col):7.2f}  p95 {np.percentile(col, 95):7.2f}  max {col.max():7.2f} us")
