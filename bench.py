@@ -56,6 +56,10 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="no HIP-event timing of the scan kernel")
     ap.add_argument("--force-exchange", action="store_true",
                     help="diagnostic: with one rank, still run the RCCL all-gather + merge every step")
+    ap.add_argument("--submit-stream", choices=["auto", "null", "side"], default="auto",
+                    help="stream the searches are submitted from.  auto: a non-default stream when pipelining "
+                         "(the NULL stream synchronises implicitly with every blocking stream of the process: "
+                         "0.332 -> 0.324 ms per batch at 1.25 M rows per rank), the NULL stream otherwise")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
     return ap.parse_args()
 
@@ -174,6 +178,10 @@ def main():
         if not args.sync:
             index.finish()
 
+    if args.submit_stream == "side" or (args.submit_stream == "auto" and pipeline):
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(side)
     for i in range(args.warmup):
         step(i)
     finish()
