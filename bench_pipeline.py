@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--store", action="store_true",
                     help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
     ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
+    ap.add_argument("--bm25", action="store_true", help="BM25 + RRF fusion in stage 1, like the reference's default")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of the timed region (stderr)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
@@ -43,7 +44,7 @@ def main():
     pc = PipelineConfig(stage1_model=args.stage1, stage2_model=args.stage2, stage3_model=args.stage3,
                         device="cuda", cache_dir="/tmp/ts_models", index_dir="/tmp/ts_index",
                         log_file="/tmp/ts_pipeline.log", log_level="WARNING",
-                        stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=False,
+                        stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=args.bm25,
                         stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
                         stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
                         stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs)
@@ -91,7 +92,7 @@ def main():
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
                    "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
-                   "queries_per_search_many": args.many},
+                   "queries_per_search_many": args.many, "bm25_rrf": args.bm25},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,
