@@ -48,3 +48,27 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle-free", ""), f"{f} mentions the oracle"
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Argument validation happens before any HIP call: negative status + a thread-local message
+    (the reference's counterpart: Python exceptions, SURVEY.md 8b 'Error convention')."""
+    from tristage_rag_amd import _lib
+    lib = _lib.load()
+    off = (ctypes.c_int32 * 2)(0, 1)
+    bad = (ctypes.c_int32 * 2)(1, 0)
+    out = ctypes.c_void_p(1)   # never dereferenced: the calls fail first
+    # null query pointer
+    assert lib.ts_maxsim_indexed_batch(None, off, 1, out, out, out, off, 8, _lib.TS_BF16, 0, out, 0, None) == _lib.TS_ERR_INVALID
+    assert b"maxsim_indexed_batch" in lib.ts_last_error()
+    # decreasing offsets
+    assert lib.ts_maxsim_indexed_batch(out, bad, 1, out, out, out, off, 8, _lib.TS_BF16, 0, out, 0, None) == _lib.TS_ERR_INVALID
+    assert b"non-decreasing" in lib.ts_last_error()
+    # bad mode / dtype
+    assert lib.ts_maxsim(out, 1, out, out, 1, 8, 7, 0, out, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_maxsim_indexed(out, 1, out, out, out, 1, 8, _lib.TS_F16, 5, out, 0, None) == _lib.TS_ERR_INVALID
+    # nothing to do is not an error
+    assert lib.ts_maxsim_indexed_batch(out, off, 0, out, out, out, off, 8, _lib.TS_BF16, 0, out, 0, None) == _lib.TS_OK
+    assert lib.ts_maxsim(out, 1, out, out, 0, 8, _lib.TS_F32, 0, out, 0, None) == _lib.TS_OK
+    with pytest.raises(Exception):
+        _lib.check(_lib.TS_ERR_INVALID)
