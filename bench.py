@@ -61,6 +61,13 @@ def parse_args():
                          "(the NULL stream synchronises implicitly with every blocking stream of the process: "
                          "0.332 -> 0.324 ms per batch at 1.25 M rows per rank), the NULL stream otherwise")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--step-events", choices=["auto", "on", "off"], default="auto",
+                    help="one HIP event per timed step on the submitting stream -> ms_per_step_min/max "
+                         "(a few microseconds each in-stream).  auto: on for N=1, off for N>1")
+    ap.add_argument("--no-encode-leg", action="store_true",
+                    help="skip the secondary leg (bi-encoder forward of the 64 query texts + the same search)")
+    ap.add_argument("--encoder", default=None,
+                    help="bi-encoder of the secondary leg (default: random:bert with hidden = --dim)")
     return ap.parse_args()
 
 
@@ -111,6 +118,51 @@ def cpu_baseline(args, torch):
         "sample": (f"{n} of {args.rows} rows x {args.dim} fp32, batch {args.batch}, top-{k}; "
                    f"{reps} reps of {t * 1e3:.1f} ms, scaled x{scale:.1f} to the full corpus"),
     }
+
+
+def encode_leg(args, torch, index, device, tdt, steps, world):
+    """Secondary, separately reported: the same stage-1 search fed by the bi-encoder instead of
+    pre-encoded queries — tokenise 64 synthetic query texts, one bf16 forward of a randomly
+    initialised BERT-base-shaped encoder (no weights exist offline), x/(|x|+1e-8), cast to the
+    index dtype, search.  Every rank encodes the (replicated) queries itself, as in §8e."""
+    import numpy as np
+    from tristage_rag_amd.encoders import SentenceEncoder
+    if args.dim % 64:
+        return None
+    spec = args.encoder or f"random:bert:{args.dim}:12:{args.dim // 64}"
+    enc = SentenceEncoder(spec, device=str(device))
+    rng = np.random.default_rng(99)
+    vocab = [f"w{i}" for i in range(5000)]
+    texts = [[" ".join(rng.choice(vocab, size=int(rng.integers(4, 16)))) for _ in range(args.batch)] for _ in range(4)]
+
+    def one(i, async_):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            e = enc.encode(texts[i % 4], batch_size=args.batch, convert_to_numpy=False, convert_to_tensor=True)
+        q = (e / (e.norm(dim=1, keepdim=True) + 1e-8)).to(tdt)
+        return index.search(q, args.k, async_=True) if async_ else index.search(q, args.k)
+
+    for i in range(2):
+        one(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i, True)
+    index.finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    te = time.perf_counter()
+    for i in range(4):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            enc.encode(texts[i % 4], batch_size=args.batch, convert_to_numpy=False, convert_to_tensor=True)
+    torch.cuda.synchronize()
+    enc_ms = (time.perf_counter() - te) / 4 * 1e3
+    return {"encode_plus_stage1_qps": round(args.batch * steps / dt, 2), "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 4), "encode_ms_per_batch": round(enc_ms, 4),
+            "encoder": spec + " (random init, hash tokenizer, bf16 autocast)"}
 
 
 def main():
@@ -199,14 +251,21 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    step_events = args.step_events == "on" or (args.step_events == "auto" and world == 1)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if step_events else []
     t0 = time.perf_counter()
+    if evs:
+        evs[0].record()
     for i in range(args.steps):
         D, I = step(i)
+        if evs:
+            evs[i + 1].record()   # on the submitting stream, which every batch's result is ordered on
     finish()                     # completes AND verifies every batch of the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)] if evs else []
     tm = local.timings(reset=True)
     info = local.last_search_info()
     if world > 1:
@@ -238,15 +297,29 @@ def main():
                 "avg_kernel_ms": round(avg_ms, 4), "launches": scan_cnt,
                 "algorithmic_bytes_per_launch": alg_bytes}
 
+    enc_leg = None
+    if not args.no_encode_leg:
+        try:
+            enc_leg = encode_leg(args, torch, index, device, tdt, max(4, min(args.steps, 20)), world)
+        except Exception as e:  # the secondary leg must never take the headline measurement down
+            enc_leg = {"error": repr(e)}
+
+    def _rows_label(n):
+        return f"{n // 1_000_000}M" if n % 1_000_000 == 0 and n >= 1_000_000 else (
+            f"{n / 1e6:g}M" if n >= 1_000_000 else str(n))
+
     if rank == 0:
         out = {
-            "metric": "end-to-end queries/sec @10Mx768 corpus (stage-1 exact top-k)",
+            "metric": (f"end-to-end queries/sec @{_rows_label(args.rows)}x{args.dim} corpus "
+                       "(stage-1 exact top-k, pre-encoded HBM-resident queries)"),
             "value": round(args.batch * args.steps / elapsed, 2),
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step_min": round(min(step_ms), 4) if step_ms else None,
+            "ms_per_step_max": round(max(step_ms), 4) if step_ms else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -265,6 +338,7 @@ def main():
                        "search_path": info["path"], "max_candidates_per_query": info["max_candidates"],
                        "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]}},
             "roofline": roof,
+            "secondary": enc_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, torch)

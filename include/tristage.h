@@ -15,9 +15,19 @@
  *     the default stream);
  *   - the library owns the corpus memory after ts_index_add; the caller owns
  *     every output buffer; a handle is freed only by ts_index_destroy;
- *   - threading: ts_index_search on a built index may not run concurrently on
- *     ONE handle (it uses the handle's workspace); use one handle per GPU rank.
- *     add / reset / destroy need exclusive access.
+ *   - threading: ts_index_search on a built index is safe for
+ *     concurrent callers on ONE handle that use distinct streams and output
+ *     buffers: each call takes one of 4 internal workspace sets (a 5th
+ *     synchronous caller waits for a set), its own report slot, and the exact
+ *     fallback of a synchronous call runs on that call's set.  Host-pointer
+ *     searches (TS_FLAG_HOST_PTR) share one staging area and are serialised
+ *     inside the handle, as are searches while per-phase profiling is on.
+ *     Asynchronous submission (TS_FLAG_ASYNC + ts_index_finish) is for ONE
+ *     submitting thread per handle at a time; synchronous searches from other
+ *     threads may run beside it.  add / reset / reserve / set_id_offset /
+ *     destroy need exclusive access.  The stateless entry points (ts_merge_topk*,
+ *     ts_maxsim*) are thread-safe; per-kernel device attributes are set once per
+ *     device under a lock, so one process may drive several GPUs.
  */
 #ifndef TRISTAGE_H_
 #define TRISTAGE_H_
@@ -91,6 +101,16 @@ int ts_index_add(ts_index* h, const void* rows, int64_t n, int32_t rows_dtype,
 int ts_index_search(ts_index* h, const void* queries, int32_t nq,
                     int32_t q_dtype, int32_t k, float* out_scores,
                     int64_t* out_ids, uint32_t flags, void* stream);
+
+/* ---- all scores, no selection -----------------------------------------------
+ * replaces the numpy product in EmbeddingService.similarity (reference
+ * src/embedding_service.py:228-237: cosine of one query against a document
+ * matrix, result in document order): out[q*ld + row] = <query q, row> for every
+ * row; ld is a multiple of 4 and >= ntotal rounded up to 32 (the entries
+ * [ntotal, that bound) of each line are set to -FLT_MAX), `out` device memory,
+ * 16-byte aligned.  Synchronous with respect to `stream` on return.            */
+int ts_index_scores(ts_index* h, const void* queries, int32_t nq, int32_t q_dtype,
+                    float* out, int64_t ld, void* stream);
 
 /* ---- asynchronous searches ------------------------------------------------
  * With TS_FLAG_ASYNC ts_index_search only enqueues work on `stream` and returns;
@@ -198,6 +218,16 @@ int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, const int64
                       const double* len_norm, double k1p1);
 int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
                    double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream);
+
+/* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
+ * if device < 0).  No MaxSim launch may be pending on that device.               */
+int ts_maxsim_release_scratch(int32_t device);
+
+/* ---- diagnostics (no GPU needed) -------------------------------------------
+ * Exercises the per-device one-time table that guards hipFuncSetAttribute with
+ * n_threads racing host threads over n_devices device numbers; 0 = every
+ * (kernel, device) action ran exactly once, failed actions were retried.      */
+int ts_selftest_device_once(int32_t n_threads, int32_t n_devices);
 
 /* ---- misc ---------------------------------------------------------------- */
 const char* ts_last_error(void);

@@ -321,3 +321,78 @@ def ndcg_at_k(qrels: Dict[str, Dict[str, int]], results: Dict[str, Dict[str, flo
         idcg = sum(g / math.log2(r + 2) for r, g in enumerate(ideal))
         vals.append(dcg / idcg if idcg > 0 else 0.0)
     return float(np.mean(vals)) if vals else 0.0
+
+
+# --------------------------------------------------------------------- parity checks
+def check_topk(D, I, corpus, queries, k, id_offset=0, score_tol=1e-3, tie_tol=2e-6):
+    """(D, I) from the HIP path vs the float64 oracle on the SAME quantised inputs.
+
+    Bar (BASELINE.json north_star): bit-exact top-k doc ids, scores within 1e-3.
+    fp32 accumulation order on the GPU differs from float64, so two scores closer than
+    `tie_tol` may legitimately swap; a difference in ids is accepted ONLY if the oracle's own
+    float64 scores of the ids involved differ by < tie_tol — never by count.
+    Returns the number of positions where ids differed (all explained)."""
+    D = np.asarray(D)
+    I = np.asarray(I)
+    D0, I0 = ip_topk(corpus, queries, k, f64=True, id_offset=id_offset)
+    n = corpus.shape[0]
+    kk = min(k, n)
+    assert D.shape == D0.shape and I.shape == I0.shape
+    assert (I[:, kk:] == -1).all()          # padding
+    assert (D[:, kk:] <= -3.0e38).all()
+    swaps = 0
+    for q in range(queries.shape[0]):
+        if np.array_equal(I[q, :kk], I0[q, :kk]):
+            np.testing.assert_allclose(D[q, :kk], D0[q, :kk], atol=score_tol, rtol=0)
+            continue
+        s = scores_f64(corpus, queries[q])
+        got = I[q, :kk] - id_offset
+        assert got.min() >= 0 and got.max() < n, "id out of range"
+        assert len(set(got.tolist())) == kk, "duplicate ids in the result"
+        sg = s[got]
+        # returned scores match the oracle's score of the SAME id
+        np.testing.assert_allclose(D[q, :kk], sg, atol=score_tol, rtol=0)
+        # order is descending up to near-ties; exact ties by ascending id
+        dif = np.diff(sg)
+        assert (dif <= tie_tol).all(), f"query {q}: result not sorted (max inversion {dif.max()})"
+        # nothing better than the boundary was left out
+        kth = np.sort(s)[::-1][kk - 1]
+        assert sg.min() >= kth - tie_tol, f"query {q}: a returned id is below the k-th best score"
+        left_out = np.setdiff1d(I0[q, :kk] - id_offset, got)
+        assert (s[left_out] <= sg.min() + tie_tol).all(), f"query {q}: a better id was left out"
+        swaps += int((I[q, :kk] != I0[q, :kk]).sum())
+    return swaps
+
+
+def check_topk_sparse(d_row, i_row, ref_ids, fetch_rows, query, score_tol=1e-3, tie_tol=2e-6):
+    """The same rule where a float64 oracle over the whole corpus is too slow (10 M / 50 M rows):
+    `ref_ids` = top-k ids of an INDEPENDENT float32 reference (e.g. a rocBLAS GEMM + torch.topk on
+    the same quantised data); `fetch_rows(ids) -> float32 [len(ids), d]` returns those corpus rows.
+    Float64 oracle scores are computed for the union of both id sets only; every id on which the
+    two results differ must sit within `tie_tol` (float64) of the k-th boundary.  Any row outside
+    the union scored below the reference's k-th entry in the reference's own arithmetic, i.e. it
+    cannot beat the boundary by more than that reference's rounding error.
+    Returns the number of ids that differed (all explained)."""
+    d_row = np.asarray(d_row, dtype=np.float32)
+    got = np.asarray(i_row, dtype=np.int64)
+    ref = np.asarray(ref_ids, dtype=np.int64)
+    k = got.shape[0]
+    assert len(set(got.tolist())) == k, "duplicate ids in the result"
+    union = np.union1d(got, ref)
+    s = scores_f64(fetch_rows(union), query)          # float64 accumulation, as in ip_topk
+    pos = {int(u): j for j, u in enumerate(union)}
+    sg = np.array([s[pos[int(i)]] for i in got])
+    np.testing.assert_allclose(d_row, sg, atol=score_tol, rtol=0)
+    dif = np.diff(sg)
+    assert (dif <= tie_tol).all(), f"result not sorted (max inversion {dif.max()})"
+    eq = np.nonzero(dif == 0.0)[0]
+    assert (got[eq + 1] > got[eq]).all(), "exact ties must come in ascending id order"
+    only_got = np.setdiff1d(got, ref)
+    only_ref = np.setdiff1d(ref, got)
+    if only_got.size or only_ref.size:
+        kth = np.sort(s)[::-1][k - 1]                 # boundary among everything either side returned
+        for i in only_ref:
+            assert s[pos[int(i)]] <= kth + tie_tol, f"id {int(i)} (score {s[pos[int(i)]]}) left out above the boundary {kth}"
+        for i in only_got:
+            assert s[pos[int(i)]] >= kth - tie_tol, f"id {int(i)} (score {s[pos[int(i)]]}) returned from below the boundary {kth}"
+    return int(only_got.size)

@@ -4,11 +4,13 @@ where a float64 oracle over everything would take too long:
   * a planted document (query itself, scaled) is returned first with its exact id;
   * results are sorted, ids unique and in range;
   * the filter path and the exact dense path agree bit for bit;
-  * a sub-sample of queries is checked against the oracle in full."""
+  * a sub-sample of queries is checked against the oracle in full (1.25 M rows), or — at 10 M and
+    50 M rows — against an independent fp32 reference with every id difference explained by a
+    float64 near-tie (helpers.check_topk_sparse; no "at most N mismatches" allowances)."""
 import numpy as np
 import pytest
 
-from helpers import check_topk
+from helpers import check_topk, check_topk_sparse
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -91,9 +93,18 @@ def test_headline_config_10m_x_768_on_one_gpu():
     qs = q[sel].float()
     ref = torch.cat([qs @ b.float().T for b in blocks], dim=1)  # [4, n] fp32
     Dr, Ir = torch.topk(ref, k, dim=1)
-    for j, qi in enumerate(sel):
-        got, want = set(I[qi].tolist()), set(Ir[j].tolist())
-        assert len(got ^ want) <= 4                              # only boundary near-ties may differ
+    def fetch(ids):                                              # corpus rows by global id
+        t = torch.as_tensor(ids, device="cuda")
+        out = torch.empty((len(ids), d), dtype=torch.float32, device="cuda")
+        for c, b in enumerate(blocks):
+            m = (t >= c * chunk) & (t < (c + 1) * chunk)
+            if bool(m.any()):
+                out[m] = b[t[m] - c * chunk].float()
+        return out.cpu().numpy()
+
+    qn = q.float().cpu().numpy()
+    for j, qi in enumerate(sel):                                 # every id difference explained by a float64 near-tie
+        check_topk_sparse(D[qi].cpu().numpy(), I[qi].cpu().numpy(), Ir[j].cpu().numpy(), fetch, qn[qi])
         assert torch.allclose(D[qi], Dr[j], atol=1e-3)
     idx.close()
 
@@ -138,8 +149,17 @@ def test_cfg4_corpus_50m_x_1024_bf16_on_one_gpu():
     qs = q[sel].float()
     ref = torch.cat([qs @ block(c).float().T for c in range(n // chunk)], dim=1)   # [2, n] fp32
     Dr, Ir = torch.topk(ref, k, dim=1)
-    for j, qi in enumerate(sel):
-        got, want = set(I[qi].tolist()), set(Ir[j].tolist())
-        assert len(got ^ want) <= 4                              # only boundary near-ties may differ
+    def fetch(ids):                                              # rows by global id: their blocks are regenerated
+        ids = np.asarray(ids)
+        out = np.empty((len(ids), d), dtype=np.float32)
+        for c in np.unique(ids // chunk):
+            m = (ids // chunk) == c
+            out[m] = block(int(c))[torch.as_tensor(ids[m] - c * chunk, device="cuda")].float().cpu().numpy()
+        return out
+
+    qn = q.float().cpu().numpy()
+    for j, qi in enumerate(sel):                                 # every id difference explained by a float64 near-tie
+        check_topk_sparse(D[qi].cpu().numpy(), I[qi].cpu().numpy(), Ir[j].cpu().numpy(), fetch, qn[qi],
+                          score_tol=2e-3)
         assert torch.allclose(D[qi], Dr[j], atol=2e-3)
     idx.close()

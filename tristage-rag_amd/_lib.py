@@ -30,6 +30,7 @@ SIGNATURES = {
     "ts_index_add": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_uint32, c_void_p]),
     "ts_index_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                   c_void_p, c_uint32, c_void_p]),
+    "ts_index_scores": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
     "ts_index_ntotal": (c_int64, [c_void_p]),
     "ts_index_dim": (c_int32, [c_void_p]),
     "ts_index_dtype": (c_int32, [c_void_p]),
@@ -56,6 +57,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, ctypes.c_double]),
     "ts_bm25_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                  POINTER(c_int32), c_void_p]),
+    "ts_maxsim_release_scratch": (c_int32, [c_int32]),
+    "ts_selftest_device_once": (c_int32, [c_int32, c_int32]),
     "ts_last_error": (c_char_p, []),
     "ts_abi_version": (c_int32, []),
 }

@@ -26,6 +26,40 @@ void ts_set_error(const char* fmt, ...);
     if (s_ != TS_OK) return s_;   \
   } while (0)
 
+// ---------------------------------------------------------------- once per device
+// hipFuncSetAttribute (MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: a
+// process that drives several GPUs (ts_index_create / ts_maxsim / ts_merge_topk all take a
+// `device`) has to set it on each of them, and two host threads may reach the first launch at
+// the same time.  One TsDeviceOnce per kernel instantiation: a bit per device, set under a
+// mutex after the action succeeded (a failed action is retried by the next caller).
+#include <atomic>
+#include <mutex>
+#define TS_MAX_DEVICES 64
+struct TsDeviceOnce {
+  std::mutex mu;
+  std::atomic<uint64_t> done{0};
+};
+template <class F>
+static inline int ts_once_per_device(TsDeviceOnce& o, int dev, F&& action) {
+  if (dev < 0 || dev >= TS_MAX_DEVICES) return action();  // untracked device: the action is idempotent
+  const uint64_t bit = 1ull << dev;
+  if (o.done.load(std::memory_order_acquire) & bit) return TS_OK;
+  std::lock_guard<std::mutex> lk(o.mu);
+  if (o.done.load(std::memory_order_relaxed) & bit) return TS_OK;
+  const int st = action();
+  if (st == TS_OK) o.done.fetch_or(bit, std::memory_order_release);
+  return st;
+}
+// the 96-160 KiB LDS kernels: allow the full 160 KiB of dynamic LDS on the CURRENT device
+static inline int ts_allow_max_lds(TsDeviceOnce& o, const void* kernel) {
+  int dev = -1;
+  TS_HIP(hipGetDevice(&dev));
+  return ts_once_per_device(o, dev, [&]() -> int {
+    TS_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return TS_OK;
+  });
+}
+
 // ---------------------------------------------------------------- layout
 //
 // The corpus is NOT kept row-major.  It is stored in the order the MFMA A

@@ -8,7 +8,11 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "ts_common.h"
 
@@ -72,7 +76,7 @@ void release(DevBuf& b) {
 
 }  // namespace
 #define TS_NPHASE 8
-#define TS_NSETS 2
+#define TS_NSETS 4         // workspace sets = synchronous searches that may run at once on one handle
 #define TS_ASYNC_SLOTS 256
 #define TS_SLOT_WORDS 80   // 64 counts + status word, padded
 namespace {
@@ -102,17 +106,28 @@ struct ts_index {
   // share a buffer that is still being read (see search_pass).
   struct WSet {
     DevBuf qimg, small, cand_score, cand_id, sample;
+    DevBuf dense, list_score, list_id;   // the dense path's score chunk and per-chunk lists
     hipEvent_t ev_pro = nullptr, ev_scan = nullptr, ev_sel = nullptr, ev_in = nullptr;  // timing disabled
     bool used = false;  // ev_sel has been recorded at least once
+    bool busy = false;  // held by a search that is being enqueued / a synchronous search in flight (h->mu)
     float* tau() { return (float*)small.p; }
     uint32_t* cand_cnt() { return (uint32_t*)small.p + 64; }
     uint32_t* status() { return (uint32_t*)small.p + 128; }
   };
   WSet ws[TS_NSETS];
   uint64_t set_next = 0;
+  // Concurrency (include/tristage.h "threading"): searches from several host threads on ONE
+  // handle are safe.  `mu` guards the set pool, the slot ring, the pending list, tickets and
+  // `info`; a search owns its WSet from acquire_set() to release_set() — a synchronous one until
+  // its result is verified (its exact fallback re-reads the set's query image), an asynchronous
+  // one only while it is being enqueued (later users are ordered behind it by ev_sel).
+  std::mutex mu;
+  std::condition_variable cv;
+  std::mutex host_mu;   // host-pointer searches share one staging area: serialised
+  std::mutex prof_mu;   // per-phase timing uses one set of events: profiled searches are serialised
+  bool slot_busy[TS_ASYNC_SLOTS] = {};
   hipStream_t s_pro = nullptr, s_scan = nullptr, s_sel = nullptr;  // TS_FLAG_PIPELINE only
-  // workspace shared by the (unpipelined) dense path and the host-pointer staging
-  DevBuf dense, list_score, list_id;
+  // staging of host-pointer calls (add / reconstruct need exclusive access anyway; searches: host_mu)
   DevBuf stage, den, qstage, out_s, out_i;
   uint32_t* host_status = nullptr;  // pinned + mapped: written by the select kernel
   uint32_t* host_status_dev = nullptr;  // device view of host_status
@@ -248,11 +263,10 @@ extern "C" int ts_index_destroy(ts_index* h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->corpus) (void)hipFree(h->corpus);
-  DevBuf* bufs[] = {&h->dense, &h->list_score, &h->list_id, &h->stage, &h->den,
-                    &h->qstage, &h->out_s, &h->out_i};
+  DevBuf* bufs[] = {&h->stage, &h->den, &h->qstage, &h->out_s, &h->out_i};
   for (DevBuf* b : bufs) release(*b);
   for (ts_index::WSet& w : h->ws) {
-    DevBuf* wb[] = {&w.qimg, &w.small, &w.cand_score, &w.cand_id, &w.sample};
+    DevBuf* wb[] = {&w.qimg, &w.small, &w.cand_score, &w.cand_id, &w.sample, &w.dense, &w.list_score, &w.list_id};
     for (DevBuf* b : wb) release(*b);
     hipEvent_t evs[] = {w.ev_pro, w.ev_scan, w.ev_sel, w.ev_in};
     for (hipEvent_t e : evs)
@@ -295,6 +309,7 @@ extern "C" int ts_index_set_id_offset(ts_index* h, int64_t offset) {
 
 extern "C" int ts_index_last_search_info(const ts_index* h, int64_t info[4]) {
   if (!h || !info) { ts_set_error("bad arguments"); return TS_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(const_cast<ts_index*>(h)->mu);
   for (int i = 0; i < 4; ++i) info[i] = h->info[i];
   return TS_OK;
 }
@@ -374,10 +389,10 @@ static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, flo
   const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
   const int64_t chunk_rows = std::min<int64_t>(kDenseChunkRows, nblk * TS_ROWS_PER_BLOCK);
   const int64_t nch = (nblk * TS_ROWS_PER_BLOCK + chunk_rows - 1) / chunk_rows;
-  TS_CHECK(ensure(h->dense, (size_t)nq * chunk_rows * 4));
+  TS_CHECK(ensure(W.dense, (size_t)nq * chunk_rows * 4));
   if (nch > 1) {
-    TS_CHECK(ensure(h->list_score, (size_t)nq * nch * k * 4));
-    TS_CHECK(ensure(h->list_id, (size_t)nq * nch * k * 4));
+    TS_CHECK(ensure(W.list_score, (size_t)nq * nch * k * 4));
+    TS_CHECK(ensure(W.list_id, (size_t)nq * nch * k * 4));
   }
   for (int64_t c = 0; c < nch; ++c) {
     const int64_t row0 = c * chunk_rows;
@@ -391,12 +406,12 @@ static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, flo
     sp.blk0 = row0 / TS_ROWS_PER_BLOCK;
     sp.blk_stride = 1;
     sp.ntotal = N;
-    sp.dense = (float*)h->dense.p;
+    sp.dense = (float*)W.dense.p;
     sp.dense_ld = chunk_rows;
     TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s));
     SelParams p{};
     p.mode = SEL_DENSE;
-    p.scores = (const float*)h->dense.p;
+    p.scores = (const float*)W.dense.p;
     p.stride = chunk_rows;
     p.n = (uint32_t)rows;
     p.id_base = (int32_t)row0;
@@ -407,8 +422,8 @@ static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, flo
       p.out_stride = k;
       p.id_offset = h->id_offset;
     } else {
-      p.out_scores = (float*)h->list_score.p + c * k;
-      p.out_ids32 = (int32_t*)h->list_id.p + c * k;
+      p.out_scores = (float*)W.list_score.p + c * k;
+      p.out_ids32 = (int32_t*)W.list_id.p + c * k;
       p.out_stride = nch * k;
     }
     TS_CHECK(ts_launch_select(p, nq, s));
@@ -416,8 +431,8 @@ static int dense_path(ts_index* h, ts_index::WSet& W, int nq, int qh, int k, flo
   if (nch > 1) {
     SelParams p{};
     p.mode = SEL_PAIRS32;
-    p.scores = (const float*)h->list_score.p;
-    p.ids32 = (const int32_t*)h->list_id.p;
+    p.scores = (const float*)W.list_score.p;
+    p.ids32 = (const int32_t*)W.list_id.p;
     p.stride = nch * k;
     p.n = (uint32_t)(nch * k);
     p.k = k;
@@ -442,6 +457,7 @@ __global__ void head_start_kernel(int us, int max_iter) {
 }
 
 static int ensure_streams(ts_index* h) {
+  std::lock_guard<std::mutex> lk(h->mu);
   if (h->s_pro) return TS_OK;
   // The scan stream outranks the two helper streams: when a scan and the previous
   // search's select become runnable at the same instant (both wait for the same scan
@@ -450,8 +466,8 @@ static int ensure_streams(ts_index* h) {
   int lo = 0, hi = 0;  // numerically lower = higher priority
   TS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   TS_HIP(hipStreamCreateWithPriority(&h->s_scan, hipStreamNonBlocking, hi));
-  TS_HIP(hipStreamCreateWithPriority(&h->s_pro, hipStreamNonBlocking, lo));
   TS_HIP(hipStreamCreateWithPriority(&h->s_sel, hipStreamNonBlocking, lo));
+  TS_HIP(hipStreamCreateWithPriority(&h->s_pro, hipStreamNonBlocking, lo));   // (last: it is the "created" flag)
   return TS_OK;
 }
 
@@ -466,8 +482,66 @@ static int ensure_streams(ts_index* h) {
 // for Sel: P of the NEXT search and Sel of the PREVIOUS one then run beside the current S, which
 // leaves an eighth of the CUs free and is HBM-bound anyway.  Passes alternate between two
 // workspace sets; a set is reused only after the Sel that last read it (its ev_sel).
+// ---- the set pool and the report-slot ring (both under h->mu)
+static ts_index::WSet* acquire_set(ts_index* h) {
+  std::unique_lock<std::mutex> lk(h->mu);
+  for (;;) {
+    for (int t = 0; t < TS_NSETS; ++t) {
+      ts_index::WSet& w = h->ws[(h->set_next + t) % TS_NSETS];
+      if (!w.busy) {
+        h->set_next = (h->set_next + t + 1) % TS_NSETS;   // round robin: pipelined searches alternate sets
+        w.busy = true;
+        return &w;
+      }
+    }
+    h->cv.wait(lk);   // TS_NSETS synchronous searches in flight: wait for one to return
+  }
+}
+static void release_set(ts_index* h, ts_index::WSet* w) {
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    w->busy = false;
+  }
+  h->cv.notify_one();
+}
+// a free slot of the mapped host ring (at most 64 asynchronous passes + TS_NSETS synchronous ones hold one)
+static int alloc_slot(ts_index* h) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  for (int t = 0; t < TS_ASYNC_SLOTS; ++t) {
+    const int sl = (int)((h->slot_next + t) % TS_ASYNC_SLOTS);
+    if (!h->slot_busy[sl]) {
+      h->slot_busy[sl] = true;
+      h->slot_next = (uint64_t)sl + 1;
+      return sl;
+    }
+  }
+  return -1;
+}
+static void free_slot(ts_index* h, int sl) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (sl >= 0 && sl < TS_ASYNC_SLOTS) h->slot_busy[sl] = false;
+}
+static void set_info(ts_index* h, int64_t a, int64_t b, int64_t c, int64_t d) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->info[0] = a; h->info[1] = b; h->info[2] = c; h->info[3] = d;
+}
+
+static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq, int q_dtype, int k,
+                          float* out_s, int64_t* out_i, uint32_t flags, hipStream_t s);
+
 static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, float* out_s,
                        int64_t* out_i, uint32_t flags, hipStream_t s) {
+  // per-phase timing shares one set of events per handle: profiled searches run one at a time
+  std::unique_lock<std::mutex> plk(h->prof_mu, std::defer_lock);
+  if (h->profiling) plk.lock();
+  ts_index::WSet* W = acquire_set(h);
+  const int st = search_pass_on(h, *W, dq, nq, q_dtype, k, out_s, out_i, flags, s);
+  release_set(h, W);
+  return st;
+}
+
+static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq, int q_dtype, int k,
+                          float* out_s, int64_t* out_i, uint32_t flags, hipStream_t s) {
   const int64_t N = h->ntotal;
   const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
   const int qh = nq > 32 ? 2 : 1;
@@ -477,8 +551,8 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   const bool pipe = filter && async && (flags & TS_FLAG_PIPELINE) != 0;
   if (pipe) TS_CHECK(ensure_streams(h));
   hipStream_t sP = pipe ? h->s_pro : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
-  ts_index::WSet& W = h->ws[h->set_next++ % TS_NSETS];
-  // the set may still be in use by the search that had it last (only possible after pipelined ones)
+  // the set may still be in use on the GPU by the (asynchronous) search that had it last, possibly
+  // on another stream
   if (W.used) TS_HIP(hipStreamWaitEvent(sP, W.ev_sel, 0));
   // the output buffers may be memory the caller's stream is still reading (a recycled
   // allocation): the final phase must not start before the stream's work issued so far
@@ -490,7 +564,7 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   prof_mark(h, 0, sP);
   TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), sP));
   if (!filter) {
-    h->info[0] = 0; h->info[1] = 0; h->info[2] = 0; h->info[3] = 0;
+    set_info(h, 0, 0, 0, 0);
     prof_mark(h, 5, s);
     TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
@@ -599,18 +673,23 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
   p.id_offset = h->id_offset;
   p.status = W.status();
   // the select kernel reports the candidate counts and the status word straight
-  // into mapped host memory: no copy kernel between it and the sync;
-  // synchronous searches use the extra last slot, asynchronous ones rotate through the ring
-  const int slot = async ? (int)(h->slot_next++ % TS_ASYNC_SLOTS) : TS_ASYNC_SLOTS;
+  // into mapped host memory: no copy kernel between it and the sync; every search in flight
+  // has its own slot of the ring
+  const int slot = alloc_slot(h);
+  if (slot < 0) { ts_set_error("no free report slot"); return TS_ERR_INVALID; }
   uint32_t* rep = h->host_status + (size_t)slot * TS_SLOT_WORDS;
   p.host_report = h->host_status_dev + (size_t)slot * TS_SLOT_WORDS;
   for (int i = 0; i < 65; ++i) rep[i] = 0;
-  TS_CHECK(ts_launch_select(p, nq, sL));
+  {
+    const int st_sel = ts_launch_select(p, nq, sL);
+    if (st_sel != TS_OK) { free_slot(h, slot); return st_sel; }
+  }
   TS_HIP(hipEventRecord(W.ev_sel, sL));
   W.used = true;
   if (pipe) TS_HIP(hipStreamWaitEvent(s, W.ev_sel, 0));  // later work on the caller's stream sees the result
   if (async) {
     // verified later, by ts_index_finish(); nothing here waits for the GPU
+    std::lock_guard<std::mutex> lk(h->mu);
     ts_index::Pending& pe = h->pending[h->npending];
     pe.ticket = h->next_ticket; pe.slot = slot; pe.nq = nq; pe.S = (uint32_t)S; pe.m = m;
     pe.e0 = pe.e1 = nullptr;
@@ -626,15 +705,23 @@ static int search_pass(ts_index* h, const void* dq, int nq, int q_dtype, int k, 
     return TS_OK;
   }
   prof_mark(h, -1, s);
-  TS_HIP(hipStreamSynchronize(s));
+  {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      free_slot(h, slot);
+      ts_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+      return TS_ERR_HIP;
+    }
+  }
   prof_collect(h);
   uint32_t maxc = 0;
   for (int i = 0; i < nq; ++i) maxc = std::max(maxc, rep[i]);
-  h->info[0] = 1; h->info[1] = maxc; h->info[2] = S; h->info[3] = m;
-  if (rep[64] != 0) {
+  const bool redo = rep[64] != 0;
+  free_slot(h, slot);
+  set_info(h, redo ? 2 : 1, maxc, S, m);
+  if (redo) {
     // a threshold was too high (fewer than k survivors) or too low (candidate
     // list overflowed, e.g. massive score ties): redo this pass exactly.
-    h->info[0] = 2;
     prof_mark(h, 5, s);
     TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
@@ -668,6 +755,7 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
     if (flags & TS_FLAG_HOST_PTR) { ts_set_error("TS_FLAG_ASYNC needs device pointers"); return TS_ERR_INVALID; }
     const int passes = (nq + qp - 1) / qp;
     if (passes > 4) { ts_set_error("TS_FLAG_ASYNC: at most %d queries per call", 4 * qp); return TS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(h->mu);
     if (h->npending + passes > TS_ASYNC_SLOTS / 4) {
       ts_set_error("too many unfinished asynchronous searches; call ts_index_finish()");
       return TS_ERR_INVALID;
@@ -678,7 +766,9 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
   float* ds = out_scores;
   int64_t* di = out_ids;
   const bool host = (flags & TS_FLAG_HOST_PTR) != 0;
+  std::unique_lock<std::mutex> hlk(h->host_mu, std::defer_lock);
   if (host) {
+    hlk.lock();   // one staging area per handle
     TS_CHECK(ensure(h->qstage, (size_t)nq * qrow));
     TS_CHECK(ensure(h->out_s, (size_t)nq * k * 4));
     TS_CHECK(ensure(h->out_i, (size_t)nq * k * 8));
@@ -692,7 +782,10 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
     TS_CHECK(search_pass(h, (const char*)dq + (size_t)q0 * qrow, c, q_dtype, k,
                          ds + (size_t)q0 * k, di + (size_t)q0 * k, flags, s));
   }
-  if (flags & TS_FLAG_ASYNC) ++h->next_ticket;
+  if (flags & TS_FLAG_ASYNC) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    ++h->next_ticket;
+  }
   if (host) {
     TS_HIP(hipMemcpyAsync(out_scores, ds, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
     TS_HIP(hipMemcpyAsync(out_ids, di, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
@@ -701,7 +794,63 @@ extern "C" int ts_index_search(ts_index* h, const void* queries, int32_t nq, int
   return TS_OK;
 }
 
-extern "C" int64_t ts_index_last_ticket(const ts_index* h) { return h ? h->next_ticket - 1 : -1; }
+// All inner products (no selection): the dense scan writes straight into the caller's matrix.
+extern "C" int ts_index_scores(ts_index* h, const void* queries, int32_t nq, int32_t q_dtype, float* out,
+                               int64_t ld, void* stream) {
+  if (!h) { ts_set_error("null handle"); return TS_ERR_INVALID; }
+  if (nq == 0) return TS_OK;
+  const int64_t N = h->ntotal;
+  const int64_t nblk = (N + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  if (!queries || !out || nq < 0 || !dtype_ok(q_dtype) || ld < nblk * TS_ROWS_PER_BLOCK || (ld & 3) ||
+      (reinterpret_cast<uintptr_t>(out) & 15)) {
+    ts_set_error("bad arguments to scores (ld must be a multiple of 4 and >= ntotal rounded up to 32, out 16-byte aligned)");
+    return TS_ERR_INVALID;
+  }
+  if (N == 0) { ts_set_error("No documents indexed. Call add_documents() first."); return TS_ERR_EMPTY; }
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int qp = (ts_scan_lds_bytes(h->L, 2) <= 160 * 1024) ? 64 : 32;
+  const size_t qrow = (size_t)h->L.dim * dtype_size(q_dtype);
+  for (int q0 = 0; q0 < nq; q0 += qp) {
+    const int c = std::min(qp, nq - q0);
+    const int qh = c > 32 ? 2 : 1;
+    ts_index::WSet* W = acquire_set(h);
+    int st = TS_OK;
+    if (W->used && hipStreamWaitEvent(s, W->ev_sel, 0) != hipSuccess) st = TS_ERR_HIP;
+    if (st == TS_OK)
+      st = ts_launch_qprep(h->L, (const char*)queries + (size_t)q0 * qrow, q_dtype, c, qh, (uint4*)W->qimg.p,
+                           nullptr, nullptr, s);
+    if (st == TS_OK) {
+      ScanParams sp{};
+      sp.corpus = h->corpus;
+      sp.qimg = (const uint4*)W->qimg.p;
+      sp.kg = h->L.kg;
+      sp.nq = c;
+      sp.nwork = nblk;
+      sp.blk0 = 0;
+      sp.blk_stride = 1;
+      sp.ntotal = N;
+      sp.dense = out + (size_t)q0 * ld;
+      sp.dense_ld = ld;
+      st = ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, s);
+    }
+    if (st == TS_OK && hipEventRecord(W->ev_sel, s) == hipSuccess) W->used = true;   // orders the set's next user behind this scan
+    else if (st == TS_OK) st = TS_ERR_HIP;
+    release_set(h, W);
+    if (st != TS_OK) {
+      if (st == TS_ERR_HIP) ts_set_error("HIP call failed in ts_index_scores");
+      return st;
+    }
+  }
+  TS_HIP(hipStreamSynchronize(s));
+  return TS_OK;
+}
+
+extern "C" int64_t ts_index_last_ticket(const ts_index* h) {
+  if (!h) return -1;
+  std::lock_guard<std::mutex> lk(const_cast<ts_index*>(h)->mu);
+  return h->next_ticket - 1;
+}
 
 extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_tickets, int32_t max_failed,
                                int32_t* n_failed) {
@@ -711,6 +860,7 @@ extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_ticket
   }
   DeviceGuard g(h->device);
   TS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  std::lock_guard<std::mutex> lk(h->mu);
   int nf = 0;
   uint32_t maxc = 0;
   for (int i = 0; i < h->npending; ++i) {
@@ -730,6 +880,7 @@ extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_ticket
       (void)hipEventDestroy(pe.e1);
     }
     h->info[0] = 1; h->info[2] = pe.S; h->info[3] = pe.m;
+    h->slot_busy[pe.slot] = false;
   }
   if (h->npending) h->info[1] = maxc;
   h->npending = 0;
@@ -756,6 +907,51 @@ extern "C" int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8]
     ms[i] = h->phase_ms[i];
     counts[i] = h->phase_cnt[i];
     if (reset) { h->phase_ms[i] = 0.0; h->phase_cnt[i] = 0; }
+  }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics
+// The per-device one-time table (ts_common.h TsDeviceOnce) exercised WITHOUT a GPU: n_threads host
+// threads race through n_devices device numbers; every device's action must run exactly once, a
+// failing action must be retried, and an out-of-range device must run the action every time.
+extern "C" int ts_selftest_device_once(int32_t n_threads, int32_t n_devices) {
+  if (n_threads <= 0 || n_threads > 256 || n_devices <= 0 || n_devices > TS_MAX_DEVICES) {
+    ts_set_error("bad arguments to selftest");
+    return TS_ERR_INVALID;
+  }
+  TsDeviceOnce once;
+  std::atomic<int> runs[TS_MAX_DEVICES];
+  std::atomic<int> fails[TS_MAX_DEVICES];
+  for (int i = 0; i < TS_MAX_DEVICES; ++i) { runs[i] = 0; fails[i] = 0; }
+  std::atomic<int> bad{0}, untracked{0};
+  auto worker = [&](int t) {
+    for (int rep = 0; rep < 200; ++rep) {
+      const int dev = (t + rep) % n_devices;
+      int st;
+      do {
+        st = ts_once_per_device(once, dev, [&]() -> int {
+          // the first attempt on every odd device fails: it must not be recorded as done
+          if ((dev & 1) && fails[dev].fetch_add(1) == 0) return TS_ERR_HIP;
+          runs[dev].fetch_add(1);
+          return TS_OK;
+        });
+      } while (st != TS_OK);
+      if (!(once.done.load() & (1ull << dev))) bad.fetch_add(1);
+    }
+    (void)ts_once_per_device(once, TS_MAX_DEVICES + t, [&]() -> int { untracked.fetch_add(1); return TS_OK; });
+    (void)ts_once_per_device(once, -1, [&]() -> int { untracked.fetch_add(1); return TS_OK; });
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+  for (std::thread& x : th) x.join();
+  for (int d = 0; d < n_devices; ++d)
+    if (runs[d].load() != 1) { ts_set_error("device %d: action ran %d times", d, runs[d].load()); return TS_ERR_INVALID; }
+  for (int d = n_devices; d < TS_MAX_DEVICES; ++d)
+    if (runs[d].load() != 0 || (once.done.load() & (1ull << d))) { ts_set_error("device %d touched", d); return TS_ERR_INVALID; }
+  if (bad.load() || untracked.load() != 2 * n_threads) {
+    ts_set_error("bit missing after success (%d) or untracked runs %d != %d", bad.load(), untracked.load(), 2 * n_threads);
+    return TS_ERR_INVALID;
   }
   return TS_OK;
 }

@@ -557,15 +557,33 @@ int scratch_get(int device, hipStream_t stream, size_t bytes, void** out) {
 }
 }  // namespace
 
+// frees the (device, stream) scratch buffers of `device` (all of them for device < 0); the caller
+// guarantees no MaxSim launch is pending there
+extern "C" int ts_maxsim_release_scratch(int32_t device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+    if (device < 0 || it->first.first == device) {
+      if (it->second.ptr) {
+        (void)hipSetDevice(it->first.first);
+        (void)hipStreamSynchronize(it->first.second);
+        (void)hipFree(it->second.ptr);
+      }
+      it = g_scratch.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return TS_OK;
+}
+
 template <int DT, int NQT, bool FULL>
 static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s, int nq = 1) {
   auto kern = maxsim16_kernel<DT, NQT, FULL>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static TsDeviceOnce lds_attr;  // per instantiation, per device (ts_common.h)
+  TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
   hipLaunchKernelGGL(kern, dim3(grid, p.passes, nq), dim3(M16_THREADS), lds, s, p);
   TS_HIP(hipGetLastError());
   return TS_OK;

@@ -326,13 +326,8 @@ static int launch_scan_t(const TsLayout& L, const ScanParams& p, int num_cus,
                          hipStream_t stream) {
   const size_t lds = (size_t)L.kg * QH * 1024 + (MODE == SCAN_FILTER ? sizeof(StageLds) : 0);
   auto kern = scan_kernel<DT, QH, MODE>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
-    attr_set = true;
-  }
+  static TsDeviceOnce lds_attr;  // per instantiation, per device (ts_common.h)
+  TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
   // The fused scan is HBM-bound with one 8-wave workgroup per CU (more waves measured
   // slower: 16 waves/CU -1.5 %); the short dense scans (sample, small corpora) are
   // latency-bound and take a second workgroup per CU when LDS allows.

@@ -422,12 +422,8 @@ static int launch_select_t(const SelParams& p, int nq, hipStream_t stream) {
   const size_t lds = ((size_t)lds_keys + SEL_OUT_CAP + (MODE == SEL_MERGE64 ? SEL_TIE_CAP : 0)) * 8 +
                      (256 + 8 + 4) * 4;
   auto kern = select_kernel<MODE>;
-  static bool attr_set = false;  // per instantiation (one process drives one GPU)
-  if (!attr_set) {
-    TS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static TsDeviceOnce lds_attr;  // per instantiation, per device (ts_common.h)
+  TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
   hipLaunchKernelGGL(kern, dim3(nq), dim3(SEL_THREADS), lds, stream, p, lds_keys);
   TS_HIP(hipGetLastError());
   return TS_OK;

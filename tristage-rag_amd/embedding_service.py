@@ -4,8 +4,10 @@ Mirror of reference src/embedding_service.py (a singleton wrapper with an
 md5-keyed FIFO cache of 1000 embeddings, text validation 1..10000 chars,
 ``encode_query`` :152-170, ``encode_document`` :172-226, cosine ``similarity``
 :228-237).  Nothing in the reference imports it; it is kept as a thin layer over
-the same SentenceEncoder the stage-1 retriever uses, and ``similarity`` runs on
-the MI355X index kernel when the document matrix is large.
+the same SentenceEncoder the stage-1 retriever uses.  ``similarity`` computes the
+same cosine; for a large document matrix on a machine with a GPU the products are
+taken by the HIP dense scan (``FlatIPIndex.scores`` -> ``ts_index_scores``), else by
+numpy exactly as the reference does.
 """
 from __future__ import annotations
 
@@ -150,13 +152,44 @@ class EmbeddingService:
                 got[i] = e
         return np.array([got[i] for i in range(len(documents))])
 
-    def similarity(self, query_embedding: np.ndarray, document_embeddings: np.ndarray) -> np.ndarray:
-        """Cosine similarity, shape (1, N) (reference :228-237)."""
+    GPU_SIMILARITY_MIN_ELEMS = 1 << 22   # below this the upload costs more than numpy's product
+
+    def similarity(self, query_embedding: np.ndarray, document_embeddings: np.ndarray,
+                   use_gpu: Optional[bool] = None) -> np.ndarray:
+        """Cosine similarity, shape (1, N) (reference :228-237).  ``use_gpu``: None = when a GPU is
+        present and the matrix is large; True/False force the HIP scan / the numpy product."""
         q = np.asarray(query_embedding)
         D = np.asarray(document_embeddings)
+        if use_gpu is None:
+            use_gpu = D.ndim == 2 and D.size >= self.GPU_SIMILARITY_MIN_ELEMS and self._gpu_present()
+        if use_gpu:
+            return self._similarity_gpu(q, D)
         qn = q / np.linalg.norm(q)
         Dn = D / np.linalg.norm(D, axis=1, keepdims=True)
         return np.dot(Dn, qn).reshape(1, -1)
+
+    @staticmethod
+    def _gpu_present() -> bool:
+        try:
+            import torch
+            return torch.cuda.is_available()
+        except Exception:
+            return False
+
+    def _similarity_gpu(self, q: np.ndarray, D: np.ndarray) -> np.ndarray:
+        """The same cosine with the N products taken on the MI355X: rows are normalised while they
+        are laid out in HBM (x/(|x|+1e-8), fp32 storage) and one dense scan writes <row, q/|q|> for
+        every row, in row order.  Differs from the numpy form by the 1e-8 in the row norm
+        (relative 1e-8 for unit-scale rows) and by fp32 accumulation order; an all-zero row gives
+        0 where numpy gives NaN."""
+        from .index import FlatIPIndex   # raises without libtristage.so / a GPU: no silent fallback
+        idx = FlatIPIndex(int(D.shape[1]), dtype="f32")
+        try:
+            idx.add(np.ascontiguousarray(D, dtype=np.float32), normalize=True)
+            qn = (q / np.linalg.norm(q)).astype(np.float32).reshape(1, -1)
+            return idx.scores(qn).astype(np.float64 if D.dtype == np.float64 else np.float32).reshape(1, -1)
+        finally:
+            idx.close()
 
     def clear_cache(self) -> None:
         self._cache.clear()

@@ -72,6 +72,8 @@ class FlatIPIndex:
         self.is_trained = True  # FAISS attribute; a flat index needs no training
         self._pending = {}      # ticket -> (q, k, D, I) of unfinished async searches
         self._pending_passes = 0
+        self._auto_redone = []  # tickets repeated by an internal finish() the caller has not seen yet
+        self.auto_finish = True  # False: the owner (ShardedFlatIPIndex) calls finish() itself, collectively
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -149,8 +151,11 @@ class FlatIPIndex:
             if not (_is_tensor(q) and q.is_cuda):
                 raise ValueError("async_ search needs a CUDA tensor")
             # the library tracks at most 64 unfinished passes (one per <= 64 queries)
-            if self._pending_passes + (q.shape[0] + 31) // 32 > 60:
-                self.finish()
+            if self.pending_room(q.shape[0]) < 0:
+                if not self.auto_finish:
+                    raise RuntimeError("too many unfinished asynchronous searches: the owner of this index "
+                                       "must call finish() (see pending_room())")
+                self._auto_redone = self.finish()   # (finish() hands back what an earlier internal one repeated)
             flags |= _lib.TS_FLAG_ASYNC
             if inputs_ready:
                 flags |= _lib.TS_FLAG_PIPELINE
@@ -188,6 +193,29 @@ class FlatIPIndex:
                          flags | _lib.TS_FLAG_HOST_PTR, 0)
         return D, I
 
+    def scores(self, q):
+        """All inner products, in row order: float32 [B, ntotal] (a CUDA tensor for tensor
+        input, numpy for numpy input).  No selection; the dense scan writes the matrix."""
+        torch = _torch()
+        was_np = not _is_tensor(q)
+        dev = torch.device("cuda", self.device)
+        qt = torch.as_tensor(np.ascontiguousarray(q, dtype=np.float32)) if was_np else q
+        if qt.dim() != 2 or qt.shape[1] != self.d:
+            raise ValueError(f"expected [B, {self.d}] queries, got {tuple(qt.shape)}")
+        if qt.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            qt = qt.float()
+        qt = qt.to(dev).contiguous()
+        n = self.ntotal
+        if n == 0:
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        ld = (n + 31) // 32 * 32
+        out = torch.empty((qt.shape[0], ld), dtype=torch.float32, device=dev)
+        _lib.check(self._lib.ts_index_scores(self._h, ctypes.c_void_p(qt.data_ptr()), qt.shape[0],
+                                             _tensor_dtype(qt), ctypes.c_void_p(out.data_ptr()), ld,
+                                             ctypes.c_void_p(_stream_ptr(self.device)) if _stream_ptr(self.device) else None))
+        out = out[:, :n]
+        return out.cpu().numpy() if was_np else out
+
     def _search_raw(self, q_ptr: int, B: int, q_dtype: int, k: int, d_ptr: int, i_ptr: int,
                     flags: int, stream: int) -> None:
         code = self._lib.ts_index_search(self._h, ctypes.c_void_p(q_ptr), B, q_dtype, k,
@@ -198,10 +226,16 @@ class FlatIPIndex:
             raise ValueError("No documents indexed. Call add_documents() first.")
         _lib.check(code)
 
+    def pending_room(self, n_queries: int) -> int:
+        """>= 0 while another asynchronous search of `n_queries` queries fits before a finish()."""
+        return 60 - self._pending_passes - (int(n_queries) + 31) // 32
+
     def finish(self):
         """Complete every asynchronous search: one stream sync, then the (rare)
         batches whose fused filter could not prove exactness are repeated on the
-        exact dense path, in place.  Returns the tickets that were repeated."""
+        exact dense path, in place.  Returns the tickets that were repeated since the
+        caller's previous finish() (including those an internal finish() — issued when
+        too many searches were pending — had to repeat)."""
         failed = (ctypes.c_int64 * 64)()
         nf = ctypes.c_int32(0)
         _lib.check(self._lib.ts_index_finish(self._h, ctypes.c_void_p(_stream_ptr(self.device)) if
@@ -214,6 +248,9 @@ class FlatIPIndex:
             redone.append(int(failed[i]))
         self._pending.clear()
         self._pending_passes = 0
+        if self._auto_redone:
+            redone = self._auto_redone + redone
+            self._auto_redone = []
         return redone
 
     def reconstruct_n(self, i0: int = 0, n: Optional[int] = None) -> np.ndarray:
@@ -270,19 +307,26 @@ def merge_topk(scores, ids, k: Optional[int] = None):
     return out_s, out_i
 
 
+def packed_layout(B: int, k: int):
+    """(offset of the int64 id block, bytes per rank) of one rank's packed partial result:
+    float32 scores [B,k], padded to a multiple of 8 bytes, then int64 ids [B,k]."""
+    ids_at = (4 * B * k + 7) & ~7
+    return ids_at, ids_at + 8 * B * k
+
+
 def merge_topk_packed(gathered, R: int, B: int, k: int):
     """Merge straight out of an all-gather buffer: `gathered` is a uint8 CUDA tensor of R
-    blocks, each = float32 scores [B,k] followed by int64 ids [B,k] (12*B*k bytes)."""
+    blocks, each laid out as packed_layout(B, k) says."""
     torch = _torch()
     lib = _lib.load()
-    nbytes = 12 * B * k
-    if gathered.dtype != torch.uint8 or gathered.numel() != R * nbytes or (B * k) % 2:
+    ids_at, nbytes = packed_layout(B, k)
+    if gathered.dtype != torch.uint8 or gathered.numel() != R * nbytes or gathered.data_ptr() % 8:
         raise ValueError("bad packed buffer")
     out_s = torch.empty((B, k), dtype=torch.float32, device=gathered.device)
     out_i = torch.empty((B, k), dtype=torch.int64, device=gathered.device)
     base = gathered.data_ptr()
     dev = gathered.device.index
-    _lib.check(lib.ts_merge_topk_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * B * k), R, B, k,
+    _lib.check(lib.ts_merge_topk_strided(ctypes.c_void_p(base), ctypes.c_void_p(base + ids_at), R, B, k,
                                          nbytes // 4, nbytes // 8, ctypes.c_void_p(out_s.data_ptr()),
                                          ctypes.c_void_p(out_i.data_ptr()), dev,
                                          ctypes.c_void_p(_stream_ptr(dev))))

@@ -59,6 +59,10 @@ class ShardedFlatIPIndex:
             local_index.reserve(max(self.hi - self.lo, 1))
         self.local_index = local_index
         self.local_index.set_id_offset(self.lo)
+        if hasattr(self.local_index, "auto_finish"):
+            # this wrapper owns the finish() cadence: a finish that repairs a batch must be followed
+            # by a repeat of that batch's exchange on EVERY rank, so it has to be the collective one
+            self.local_index.auto_finish = False
         self.merge_packed_fn = None
         if merge_fn is None:
             from .index import merge_topk, merge_topk_packed
@@ -92,17 +96,25 @@ class ShardedFlatIPIndex:
         ``async_=True``: local search, all-gather and merge are only enqueued (all
         three are stream-ordered); call :meth:`finish` before reading the result."""
         import torch
-        if not torch.is_tensor(q):  # FAISS-style numpy call: same path on host tensors, numpy back
+        if not torch.is_tensor(q):  # FAISS-style numpy call: same path, numpy back
             D, I = self.search(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)), k)
             return D.cpu().numpy(), I.cpu().numpy()
-        if async_ and len(self._pending) >= 48:
-            self.finish()
+        dev = self._index_device()
+        if dev is not None and not q.is_cuda:
+            # host queries with the HIP index underneath: the exchange buffer the local search
+            # writes into lives on the index's GPU, so the queries go there first
+            q = q.to(dev)
         B = q.shape[0]
+        if async_ and (len(self._pending) >= 48 or
+                       (hasattr(self.local_index, "pending_room") and self.local_index.pending_room(B) < 0)):
+            self.finish()   # collective: every rank sees the same sequence of batch sizes
         # the local result is produced directly inside the buffer that is exchanged:
-        # [float32 scores | int64 ids] = 12*B*k bytes, no packing kernels
+        # [float32 scores | pad to 8 | int64 ids], no packing kernels
+        from .index import packed_layout
+        ids_at, _ = packed_layout(B, k)
         packed = self._packed_buffer(B, k, q.device)
         D = packed[: 4 * B * k].view(torch.float32).view(B, k)
-        I = packed[4 * B * k:].view(torch.int64).view(B, k)
+        I = packed[ids_at:].view(torch.int64).view(B, k)
         if self.hi > self.lo:
             if getattr(self.local_index, "supports_out", False):
                 self.local_index.search(q, k, async_=async_, out=(D, I), inputs_ready=inputs_ready and async_)
@@ -123,11 +135,21 @@ class ShardedFlatIPIndex:
     def _host_staged(self) -> bool:
         return self._dist.is_initialized() and self._dist.get_backend(self.group) == "gloo"
 
+    def _index_device(self):
+        """torch device of the local HIP index (None for a stand-in index without one)."""
+        if getattr(self.local_index, "supports_out", False) and hasattr(self.local_index, "device"):
+            import torch
+            return torch.device("cuda", int(self.local_index.device))
+        return None
+
     def _packed_buffer(self, B: int, k: int, device):
         import torch
-        if (B * k) % 2:
-            raise ValueError("B*k must be even")
-        return torch.empty((12 * B * k,), dtype=torch.uint8, device=device)
+        from .index import packed_layout
+        ids_at, nbytes = packed_layout(B, k)
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        if ids_at != 4 * B * k:
+            buf[4 * B * k: ids_at] = 0     # the padding travels through the all-gather: keep it defined
+        return buf
 
     def _exchange_and_merge(self, packed, B: int, k: int):
         """ONE collective (all-gather of the packed partial results) + the merge kernel,
@@ -144,10 +166,11 @@ class ShardedFlatIPIndex:
             self._dist.all_gather_into_tensor(flat, packed, group=self.group)  # 1-D: gloo and RCCL both take it
         if self.merge_packed_fn is not None:
             return self.merge_packed_fn(flat, self.world_size, B, k)
-        ns = 4 * B * k
+        from .index import packed_layout
+        ns, ids_at = 4 * B * k, packed_layout(B, k)[0]
         blocks = flat.view(self.world_size, packed.numel())
         Dg = blocks[:, :ns].contiguous().view(torch.float32).reshape(self.world_size, B, k)
-        Ig = blocks[:, ns:].contiguous().view(torch.int64).reshape(self.world_size, B, k)
+        Ig = blocks[:, ids_at:].contiguous().view(torch.int64).reshape(self.world_size, B, k)
         return self.merge_fn(Dg, Ig)
 
     def finish(self):

@@ -1,8 +1,12 @@
-"""Importable alias of the ``tristage-rag_amd/`` package directory."""
+"""Importable name of the ``tristage-rag_amd/`` package directory (a hyphen is not a Python
+identifier): the real package is loaded from there under this name and takes this module's place."""
+import importlib.util as _ilu
 import os as _os
+import sys as _sys
 
 _real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tristage-rag_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _f
+_spec = _ilu.spec_from_file_location(__name__, _os.path.join(_real, "__init__.py"),
+                                     submodule_search_locations=[_real])
+_mod = _ilu.module_from_spec(_spec)
+_sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
