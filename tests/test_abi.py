@@ -72,3 +72,22 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.ts_maxsim(out, 1, out, out, 0, 8, _lib.TS_F32, 0, out, 0, None) == _lib.TS_OK
     with pytest.raises(Exception):
         _lib.check(_lib.TS_ERR_INVALID)
+
+
+def test_per_device_kernel_attribute_table():
+    """hipFuncSetAttribute is per device: the table that guards it (ts_common.h TsDeviceOnce) runs each
+    (kernel, device) action exactly once under racing host threads, retries a failed action and never
+    marks an untracked device.  Exercised through the library's own self-test (no GPU involved)."""
+    from tristage_rag_amd import _lib
+    lib = _lib.load()
+    for threads, devices in ((1, 1), (16, 8), (5, 64), (32, 3)):
+        assert lib.ts_selftest_device_once(threads, devices) == _lib.TS_OK, _lib.last_error()
+    assert lib.ts_selftest_device_once(0, 4) == _lib.TS_ERR_INVALID
+    assert lib.ts_selftest_device_once(4, 65) == _lib.TS_ERR_INVALID
+
+
+def test_scores_entry_point_validates_arguments_without_a_gpu():
+    from tristage_rag_amd import _lib
+    lib = _lib.load()
+    assert lib.ts_index_scores(None, None, 1, 0, None, 32, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_maxsim_release_scratch(-1) == _lib.TS_OK          # nothing allocated: nothing to free

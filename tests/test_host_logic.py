@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from doubles import OracleIndex, oracle_maxsim, oracle_maxsim_indexed, oracle_maxsim_indexed_batch
+from oracle import oracle
 from tristage_rag_amd.embedding_service import EmbeddingConfig, EmbeddingService
 from tristage_rag_amd.encoders import CrossEncoderModel, HashTokenizer, SentenceEncoder
 from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
@@ -449,3 +450,54 @@ def test_pipeline_persistence_restores_the_stage2_token_store(encoder, tmp_path)
     assert len(c.stage2.token_store) == len(DOCS)
     got = c.search("neural networks attention")
     assert [r["doc_id"] for r in got["results"]] == [r["doc_id"] for r in want["results"]]
+
+
+# ------------------------------------------------------------------ evaluation entry point (JSONL dir -> nDCG@10)
+def _write_task(dirpath, docs, queries, qrels):
+    import json as _json
+    os.makedirs(dirpath, exist_ok=True)
+    with open(os.path.join(dirpath, "corpus.jsonl"), "w") as f:
+        for i, d in enumerate(docs):
+            f.write(_json.dumps({"_id": f"d{i}", "title": "", "text": d}) + "\n")
+    with open(os.path.join(dirpath, "queries.jsonl"), "w") as f:
+        for qid, q in queries.items():
+            f.write(_json.dumps({"_id": qid, "text": q}) + "\n")
+    with open(os.path.join(dirpath, "qrels.jsonl"), "w") as f:
+        for qid, rel in qrels.items():
+            for did, sc in rel.items():
+                f.write(_json.dumps({"query-id": qid, "corpus-id": did, "score": sc}) + "\n")
+
+
+def test_evaluation_run_task_matches_oracle_ndcg(encoder, tmp_path):
+    """JSONL directory (schema of reference benchmark/limit_mteb_tasks.py:129-158) -> TriStageMTEBModel ->
+    the MTEB-style result entry; nDCG@10 equals the oracle's on the same run, in both modes."""
+    from tristage_rag_amd import evaluation as ev
+    queries = {"q1": "neural networks attention", "q2": "human language", "q3": "statistics"}
+    qrels = {"q1": {"d3": 1, "d4": 2}, "q2": {"d1": 1}, "q3": {"d0": 1, "d2": 1}}
+    _write_task(str(tmp_path / "task"), DOCS, queries, qrels)
+    corpus, qs, qr = ev.load_jsonl_dataset(str(tmp_path / "task"))
+    assert list(corpus) == [f"d{i}" for i in range(5)] and qs == queries and qr == qrels
+    m = TriStageMTEBModel(pipeline=_pipeline(encoder, tmp_path, stage1_enable_bm25=False))
+    entry = ev.run_task(m, str(tmp_path / "task"), "ToyRetrieval", mode="rerank", top_k=3)
+    run = TriStageMTEBModel(pipeline=_pipeline(encoder, tmp_path, stage1_enable_bm25=False)).search_cross_encoder(
+        corpus, qs, top_k=3)
+    sc = entry["scores"]["test"][0]
+    assert sc["ndcg_at_10"] == pytest.approx(oracle.ndcg_at_k(qrels, run, 10)) and entry["main_score"] == sc["ndcg_at_10"]
+    assert sc["ndcg_at_3"] == pytest.approx(oracle.ndcg_at_k(qrels, run, 3))
+    assert entry["num_queries"] == 3 and entry["num_documents"] == 5 and entry["task_name"] == "ToyRetrieval"
+    # dense mode: encode() for corpus and queries, cosine top-k on the (stand-in) index
+    m2 = TriStageMTEBModel(pipeline=_pipeline(encoder, tmp_path, stage1_enable_bm25=False))
+    dense = ev.dense_results(m2, corpus, qs, top_k=4, index_factory=lambda d: OracleIndex(d))
+    E = encoder.encode(DOCS, normalize_embeddings=True)
+    Q = encoder.encode(list(queries.values()), normalize_embeddings=True)
+    for r, qid in enumerate(queries):
+        want = np.argsort(-(E @ Q[r]), kind="stable")[:4]
+        assert list(dense[qid]) == [f"d{i}" for i in want]
+    entry2 = ev.run_task(m2, str(tmp_path / "task"), "ToyRetrieval", mode="dense", index_factory=lambda d: OracleIndex(d))
+    assert 0.0 <= entry2["main_score"] <= 1.0
+    # metric helpers on a hand-made run
+    run2 = {"q": {"a": 0.9, "b": 0.8, "c": 0.1}}
+    assert ev.recall_at_k({"q": {"b": 1, "z": 1}}, run2, 2) == 0.5
+    assert ev.mrr_at_k({"q": {"b": 1}}, run2, 10) == 0.5
+    with pytest.raises(ValueError):
+        ev.run_task(m2, str(tmp_path / "task"), mode="nope")

@@ -61,10 +61,11 @@ def _worker(rank, world, port, n, d, k, B, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 501, 40), (3, 100, 60), (2, 5, 8)])
-def test_sharded_search_equals_unsharded(tmp_path, world, n, k):
+@pytest.mark.parametrize("world,n,k,B", [(2, 501, 40, 6), (3, 100, 60, 6), (2, 5, 8, 6),
+                                          (2, 77, 25, 1), (3, 40, 7, 3)])     # odd B*k: ids start at an 8-byte pad
+def test_sharded_search_equals_unsharded(tmp_path, world, n, k, B):
     from oracle import oracle
-    d, B = 24, 6
+    d = 24
     mp.spawn(_worker, args=(world, _free_port(), n, d, k, B, str(tmp_path)), nprocs=world, join=True)
     corpus, queries = np.load(tmp_path / "corpus.npy"), np.load(tmp_path / "queries.npy")
     D0, I0 = oracle.ip_topk(corpus, queries, k)

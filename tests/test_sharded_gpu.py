@@ -131,3 +131,68 @@ def test_two_ranks_on_one_gpu_full_protocol(tmp_path):
     for i in range(3):
         q = make_corpus(64, d, seed=40 + i, dtype="f16")
         check_topk(D0[i][:8], I0[i][:8], corpus, q[:8], k)
+
+
+def test_sharded_numpy_call_and_odd_k_on_the_real_index():
+    """FAISS-style numpy queries through ShardedFlatIPIndex with the real HIP index underneath (the exchange
+    buffer lives on the GPU: host queries are moved there first), and an odd B*k (the int64 id block of the
+    packed buffer starts at an 8-byte pad)."""
+    import torch
+    from tristage_rag_amd.sharded import ShardedFlatIPIndex
+    n, d = 60_000, 96
+    corpus = make_corpus(n, d, dtype="f16")
+    idx = ShardedFlatIPIndex(d, n, dtype="f16", device=0)
+    idx.add_global(torch.from_numpy(corpus).cuda().half())
+    for B, k in ((7, 50), (1, 25), (3, 33)):
+        q = make_corpus(B, d, seed=70 + B, dtype="f16")
+        D, I = idx.search(q, k)                                   # numpy in -> numpy out
+        assert isinstance(D, np.ndarray) and D.shape == (B, k)
+        check_topk(D, I, corpus, q, k)
+        Dt, It = idx.search(torch.from_numpy(q), k)               # host tensor in
+        assert np.array_equal(It.cpu().numpy(), I) and np.array_equal(Dt.cpu().numpy(), D)
+
+
+def test_sharded_async_repairs_survive_many_pending_batches():
+    """with more asynchronous batches in flight than the local index tracks, a batch whose fused
+    filter failed (20 000 exact ties overflow the candidate list) must still be re-exchanged after its local
+    repair.  RCCL world of one with the exchange forced on; 80 batches, every other one failing; odd B*k too."""
+    import torch
+    import torch.distributed as dist
+    from tristage_rag_amd.sharded import ShardedFlatIPIndex
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        n, d, k = 120_000, 128, 301
+        corpus = make_corpus(n, d, seed=31, dtype="f16")
+        corpus[40_000:60_000] = corpus[11]
+        ok_q = make_corpus(9, d, seed=32, dtype="f16")
+        bad_q = ok_q.copy()
+        bad_q[4] = corpus[11]
+        idx = ShardedFlatIPIndex(d, n, dtype="f16", device=0)
+        idx.always_exchange = True
+        idx.add_global(torch.from_numpy(corpus).cuda().half())
+        qa, qb = torch.from_numpy(ok_q).cuda().half(), torch.from_numpy(bad_q).cuda().half()
+        Da, Ia = idx.search(qa, k)
+        Db, Ib = idx.search(qb, k)
+        assert idx.local_index.last_search_info()["path"] == "filter+dense-fallback"
+        check_topk(Db.cpu().numpy(), Ib.cpu().numpy(), corpus, bad_q, k)
+        torch.cuda.synchronize()
+        for ready in (False, True):
+            outs = [idx.search(qb if i % 2 else qa, k, async_=True, inputs_ready=ready) for i in range(80)]
+            idx.finish()
+            for i, (D, I) in enumerate(outs):
+                wd, wi = (Db, Ib) if i % 2 else (Da, Ia)
+                assert torch.equal(I, wi) and torch.equal(D, wd), (ready, i)
+        # the plain index: its own automatic finish() must hand the repaired tickets to the next finish()
+        li = FlatLocal = idx.local_index
+        li.auto_finish = True
+        outs = [li.search(qb if i % 2 else qa, k, async_=True) for i in range(70)]
+        redone = li.finish()
+        assert len(redone) == 35, redone
+    finally:
+        dist.destroy_process_group()

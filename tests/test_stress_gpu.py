@@ -115,3 +115,71 @@ def test_concurrent_host_threads():
     assert not errors, errors
     for idx in idxs:
         idx.close()
+
+
+def test_one_handle_many_host_threads():
+    """SURVEY.md 8b threading contract: ts_index_search on ONE handle from several host threads with distinct
+    streams and output buffers.  Filter path, exact dense path (k above the filter limit), the exact FALLBACK of
+    a failing filter (20 000 exact ties overflow the candidate list; the redo re-reads the call's own query
+    image), host-pointer calls and ts_index_scores all run at once; every result equals its single-threaded
+    value bit for bit."""
+    import threading
+    import torch
+    from tristage_rag_amd.index import FlatIPIndex
+    d, n = 128, 200_000
+    corpus = make_corpus(n, d, seed=91, dtype="f16")
+    corpus[30_000:50_000] = corpus[7]                       # massive exact ties
+    idx = FlatIPIndex(d, dtype="f16")
+    idx.add(torch.from_numpy(corpus).cuda().half())
+    base = make_corpus(64, d, seed=92, dtype="f16")
+    tie_q = base.copy()
+    tie_q[3] = corpus[7]                                    # this query's top 20 000 scores are equal
+    jobs = [dict(q=base, k=100), dict(q=make_corpus(33, d, seed=93, dtype="f16"), k=1000),
+            dict(q=tie_q, k=500), dict(q=make_corpus(64, d, seed=94, dtype="f16"), k=3000),
+            dict(q=make_corpus(5, d, seed=95, dtype="f16"), k=10, host=True),
+            dict(q=make_corpus(40, d, seed=96, dtype="f16"), scores=True)]
+    want, paths = [], []
+    for j in jobs:                                          # single-threaded reference values
+        if j.get("scores"):
+            want.append(idx.scores(torch.from_numpy(j["q"]).cuda().half()).clone())
+            paths.append("scores")
+        elif j.get("host"):
+            want.append(idx.search(j["q"], j["k"]))
+            paths.append(idx.last_search_info()["path"])
+        else:
+            D, I = idx.search(torch.from_numpy(j["q"]).cuda().half(), j["k"])
+            want.append((D.clone(), I.clone()))
+            paths.append(idx.last_search_info()["path"])
+    assert paths[:4] == ["filter", "filter", "filter+dense-fallback", "dense"], paths
+    check_topk(want[2][0].cpu().numpy()[:5], want[2][1].cpu().numpy()[:5], corpus, tie_q[:5], 500)
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(t):
+        try:
+            j = jobs[t % len(jobs)]
+            w = want[t % len(jobs)]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                qd = None if j.get("host") else torch.from_numpy(j["q"]).cuda().half()
+                for rep in range(12):
+                    if j.get("scores"):
+                        assert torch.equal(idx.scores(qd), w)
+                    elif j.get("host"):
+                        D, I = idx.search(j["q"], j["k"])
+                        assert np.array_equal(I, w[1]) and np.array_equal(D, w[0])
+                    else:
+                        D = torch.empty((qd.shape[0], j["k"]), dtype=torch.float32, device="cuda")
+                        I = torch.empty((qd.shape[0], j["k"]), dtype=torch.int64, device="cuda")
+                        idx.search(qd, j["k"], out=(D, I))
+                        assert torch.equal(I, w[1]) and torch.equal(D, w[0]), (t, rep)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(9)]   # 9 threads > 4 workspace sets
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    idx.close()
