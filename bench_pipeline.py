@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
     ap.add_argument("--bm25", action="store_true", help="BM25 + RRF fusion in stage 1, like the reference's default")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of the timed region (stderr)")
+    ap.add_argument("--ids", action="store_true",
+                    help="stage-3 token ids cached at add time: search_many runs every stage on arrays (needs --store --many)")
+    ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
     args = ap.parse_args()
@@ -47,7 +50,8 @@ def main():
                         stage1_top_k=1000, stage2_top_k=100, stage3_top_k=10, stage1_enable_bm25=args.bm25,
                         stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
                         stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
-                        stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs)
+                        stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs,
+                        stage3_cache_document_tokens=args.ids, save_intermediate_results=args.keep)
     p = RetrievalPipeline(config=pc)
     t0 = time.perf_counter()
     p.add_documents(docs)
@@ -92,7 +96,9 @@ def main():
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
                    "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
-                   "queries_per_search_many": args.many, "bm25_rrf": args.bm25},
+                   "queries_per_search_many": args.many, "bm25_rrf": args.bm25,
+                   "stage3_token_id_cache": args.ids, "save_intermediate_results": args.keep,
+                   "array_path": bool(args.ids and args.store and args.many and getattr(p.stage3, "_pairs_usable", False))},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,

@@ -501,3 +501,111 @@ def test_evaluation_run_task_matches_oracle_ndcg(encoder, tmp_path):
     assert ev.mrr_at_k({"q": {"b": 1}}, run2, 10) == 0.5
     with pytest.raises(ValueError):
         ev.run_task(m2, str(tmp_path / "task"), mode="nope")
+
+
+# ------------------------------------------------------------------ token-id pair assembly + array-level search_many
+def _bert_tokenizer(tmp_path):
+    """A REAL transformers tokenizer (WordPiece through the tokenizers crate) over a synthetic vocabulary."""
+    from transformers import BertTokenizer
+    words = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "alpha", "bravo", "charlie", "delta", "echo", "foxtrot",
+             "golf", "hotel"] + [f"w{i}" for i in range(200)]
+    vf = tmp_path / "vocab.txt"
+    vf.write_text("\n".join(words))
+    return BertTokenizer(str(vf))
+
+
+@pytest.mark.parametrize("kind", ["hash", "bert"])
+@pytest.mark.parametrize("max_length", [12, 40, 41, 256])
+def test_pair_assembler_reproduces_the_tokenizer(tmp_path, kind, max_length):
+    """Cross-encoder inputs assembled from cached token ids == tokenizer(query, doc, truncation=True, padding=True)
+    (reference src/stage3_reranker.py:139-160), including the longest-first truncation of BOTH known
+    implementations (odd and even budgets, either side longer, ties), for our hashing tokenizer and for a real
+    transformers tokenizer; the rule is probed from the tokenizer, not assumed."""
+    from tristage_rag_amd.encoders import PairAssembler
+    tok = HashTokenizer() if kind == "hash" else _bert_tokenizer(tmp_path)
+    pa = PairAssembler(tok, max_length)
+    assert pa.ok, pa.why
+    rng = np.random.default_rng(max_length)
+    vocab = [f"w{i}" for i in range(200)]
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 70)))) for _ in range(120)] + ["", "w1"]
+    qs = [" ".join(rng.choice(vocab, size=int(rng.integers(0, 60)))) for _ in range(12)] + ["", "w2 w3"]
+    pa.add_documents(docs[:50])
+    pa.add_documents(docs[50:])
+    assert len(pa) == len(docs)
+    pq = torch.from_numpy(rng.integers(0, len(qs), size=600))
+    pd = torch.from_numpy(rng.integers(0, len(docs), size=600))
+    plan = pa.plan([pa.ids_of(q) for q in qs], pq, pd, "cpu")
+    got = pa.batch(plan, torch.arange(600))
+    want = tok([qs[i] for i in pq.tolist()], [docs[i] for i in pd.tolist()], truncation=True, padding=True,
+               max_length=max_length, return_tensors="pt")
+    for k in got:
+        assert torch.equal(got[k], want[k]), k
+    assert int(plan["total"].max()) <= max_length
+    sel = torch.tensor([5, 17, 3])                                 # a sub-batch, padded to a given width
+    sub = pa.batch(plan, sel, width=int(plan["total"][sel].max()) + 2)
+    assert sub["input_ids"].shape[1] == int(plan["total"][sel].max()) + 2
+    assert torch.equal(sub["attention_mask"].sum(1), plan["total"][sel])
+
+
+def test_pair_assembler_refuses_a_tokenizer_it_cannot_restate():
+    from tristage_rag_amd.encoders import PairAssembler
+
+    class Odd(HashTokenizer):                                      # truncates only the second text
+        def __call__(self, text, text_pair=None, truncation=True, max_length=None, **kw):
+            out = super().__call__(text, text_pair, truncation=False, max_length=max_length, **kw)
+            if text_pair is not None:
+                out["input_ids"] = [r[: max_length] for r in out["input_ids"]]
+                out["token_type_ids"] = [r[: max_length] for r in out["token_type_ids"]]
+            return out
+    pa = PairAssembler(Odd(), 24)
+    assert not pa.ok and pa.why
+
+
+@pytest.mark.parametrize("bm25,fusion", [(False, "rrf"), (True, "rrf"), (True, "weighted")])
+def test_search_many_on_arrays_equals_the_record_path(encoder, tmp_path, bm25, fusion):
+    """RetrievalPipeline.search_many with every stage on arrays (ids / scores as matrices, token-store lookup,
+    token-id pair assembly, device sorts) returns the SAME records as the per-record path: identical ids,
+    fields and fused / stage-1 / stage-2 scores; stage-3 scores up to batch-padding noise."""
+    from pipeline_pairs import cpu_pipeline, synth_docs
+    docs = synth_docs(300, seed=5)
+    qs = ["neural networks attention", "vector index search doc42", "token embedding", "gpu memory doc7 doc8"]
+    kw = dict(stage1_enable_bm25=bm25, stage1_fusion_method=fusion, stage2_precompute_document_embeddings=True,
+              stage1_top_k=60, stage2_top_k=20, stage3_top_k=7)
+    a = cpu_pipeline(tmp_path, name="a", stage3_cache_document_tokens=True, **kw)
+    b = cpu_pipeline(tmp_path, name="b", **kw)
+    a.add_documents(docs[:200])
+    a.add_documents(docs[200:])                                    # incremental adds extend the id cache
+    b.add_documents(docs[:200])                                    # (same batches on both sides: same padding noise)
+    b.add_documents(docs[200:])
+    assert a.stage3._pairs_usable and a.stage3._pairs.rule == "second_on_ties"
+    took = []
+    orig = a._search_many_arrays
+    a._search_many_arrays = lambda *x, **k: (took.append(1), orig(*x, **k))[1]
+    ra, rb = a.search_many(qs, top_k=5), b.search_many(qs, top_k=5)
+    assert took == [1] and all(r["results"] for r in ra)
+    for x, y in zip(ra, rb):
+        assert set(x) == set(y) and set(x["timing"]) == set(y["timing"])
+        for st in ("stage1_results", "stage2_results", "results"):
+            assert len(x[st]) == len(y[st])
+            for u, v in zip(x[st], y[st]):
+                assert set(u) == set(v)
+                for k in u:
+                    if k == "stage3_score":
+                        assert u[k] == pytest.approx(v[k], abs=1e-5)
+                    else:
+                        assert u[k] == v[k], (st, k)
+    # without the intermediate lists only the final records are built
+    a.config.save_intermediate_results = False
+    lean = a.search_many(qs, top_k=5)
+    for x, y in zip(lean, ra):
+        assert x["stage1_results"] == [] and x["stage2_results"] == []
+        assert [r["doc_id"] for r in x["results"]] == [r["doc_id"] for r in y["results"]]
+    # fewer documents than stage1_top_k: the record path (padded results) takes over
+    small = cpu_pipeline(tmp_path, name="s", stage3_cache_document_tokens=True, **kw)
+    small.add_documents(docs[:30])
+    assert small._search_many_arrays(qs, 5) is None and len(small.search_many(qs, top_k=5)) == len(qs)
+    if bm25 and fusion == "weighted":                               # the reference divides by max(bm25) == 0 here
+        with pytest.raises(ZeroDivisionError):
+            a.search_many(["zzz"], top_k=3)
+        with pytest.raises(ZeroDivisionError):
+            b.search_many(["zzz"], top_k=3)

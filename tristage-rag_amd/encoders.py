@@ -455,6 +455,234 @@ class SentenceEncoder:
         return res.cpu().numpy() if convert_to_numpy else list(res)
 
 
+# --------------------------------------------------------------------------- pair assembly on the device
+class PairAssembler:
+    """(query, document) cross-encoder inputs built from TOKEN IDS on the GPU.
+
+    The reference hands text pairs to the tokenizer for every query (reference
+    src/stage3_reranker.py:113-118, 139-160): 100 documents are re-tokenised per query on the host.
+    Here every document is tokenised ONCE (at add_documents), its ids are kept in a padded int32
+    table in HBM, a query is tokenised once, and the batch tensors ``[prefix] q [middle] d [suffix]``
+    are gathered on the device, with the tokenizer's own longest-first truncation restated in
+    closed form.
+
+    Nothing about the tokenizer is assumed: the special-token template, the token types and the
+    truncation rule are PROBED from it (``tokenizer(a, b, truncation=True, max_length=...)`` on
+    synthetic probes, including over-long and equal-length cases) and the assembler only declares
+    itself usable (``self.ok``) if it reproduces the tokenizer's output on every probe; otherwise the
+    caller keeps tokenising text pairs."""
+
+    RULES = ("second_on_ties", "longer_gets_odd")   # transformers' python loop / the tokenizers crate's closed form
+
+    def __init__(self, tokenizer, max_length: int, pad_token_id: Optional[int] = None):
+        self.tok = tokenizer
+        self.max_length = int(max_length)
+        self.pad = int(pad_token_id if pad_token_id is not None else (getattr(tokenizer, "pad_token_id", 0) or 0))
+        self.prefix: List[int] = []
+        self.middle: List[int] = []
+        self.suffix: List[int] = []
+        self.type_b = 0
+        self.has_types = False
+        self.rule: Optional[str] = None
+        self.ok = False
+        self.why = ""
+        self._doc_ids: List[List[int]] = []     # per document slot: the first max_length ids ...
+        self._doc_len: List[int] = []           # ... and the true token count
+        self._table = None                      # (device, int32 [N, L] padded ids, int32 [N] lengths)
+        try:
+            self._probe()
+        except Exception as e:  # a tokenizer we cannot characterise: the caller keeps the text path
+            self.ok, self.why = False, f"probe failed: {e!r}"
+
+    # -- the tokenizer, one text at a time -----------------------------------------
+    def ids_of(self, text: str) -> List[int]:
+        """Token ids of one text WITHOUT special tokens and without truncation (the truncation rule needs the
+        true lengths of both texts; only the first max_length ids can ever be used)."""
+        if isinstance(self.tok, HashTokenizer):
+            return self.tok._ids(text)
+        return list(self.tok(text, add_special_tokens=False, truncation=False)["input_ids"])
+
+    def _pair(self, a: str, b: str) -> Dict[str, List[int]]:
+        enc = self.tok(a, b, truncation=True, max_length=self.max_length, padding=False)
+        out = {}
+        for k, v in enc.items():
+            if k in ("input_ids", "token_type_ids"):
+                v = list(v)
+                out[k] = list(v[0]) if v and isinstance(v[0], (list, tuple)) else v   # (HashTokenizer returns rows)
+        return out
+
+    @staticmethod
+    def _find(hay: List[int], needle: List[int], start: int = 0) -> int:
+        n = len(needle)
+        for i in range(start, len(hay) - n + 1):
+            if hay[i:i + n] == needle:
+                return i
+        return -1
+
+    def _probe(self) -> None:
+        words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel"]
+        a_txt, b_txt = "alpha bravo charlie", "delta echo foxtrot golf"
+        a, b = self.ids_of(a_txt), self.ids_of(b_txt)
+        if not a or not b:
+            self.why = "empty probe tokenisation"
+            return
+        enc = self._pair(a_txt, b_txt)
+        ids = enc["input_ids"]
+        ia = self._find(ids, a)
+        ib = self._find(ids, b, ia + len(a)) if ia >= 0 else -1
+        if ia < 0 or ib < 0:
+            self.why = "a text tokenises differently inside a pair"
+            return
+        self.prefix, self.middle, self.suffix = ids[:ia], ids[ia + len(a): ib], ids[ib + len(b):]
+        tt = enc.get("token_type_ids")
+        self.has_types = tt is not None
+        if tt is not None:
+            if any(tt[:ib]) or len(set(tt[ib:])) != 1:
+                self.why = "unexpected token-type layout"
+                return
+            self.type_b = int(tt[ib])
+        # truncation rule: probes that overflow max_length in every regime
+        budget = self.max_length - len(self.prefix) - len(self.middle) - len(self.suffix)
+        if budget < 2:
+            self.why = "max_length leaves no room"
+            return
+
+        def text_of(n, off):   # n words cycling through the list: ids_of() gives >= n tokens
+            return " ".join(words[(off + i) % len(words)] for i in range(n))
+        probes = [(3, budget + 5), (budget + 5, 3), (budget, budget), (budget // 2 + 1, budget // 2 + 1),
+                  (budget // 2 + 2, budget // 2 + 1), (budget // 2 + 1, budget // 2 + 2), (budget - 1, 2), (2, budget - 1),
+                  (budget // 2 + 7, budget // 2 + 2), (budget + 9, budget + 4), (1, 1), (budget // 3, budget)]
+        cases = []
+        for na, nb in probes:
+            ta, tb = text_of(max(na, 1), 0), text_of(max(nb, 1), 3)
+            cases.append((self.ids_of(ta), self.ids_of(tb), self._pair(ta, tb)))
+        for rule in self.RULES:
+            good = True
+            for qa, qb, want in cases:
+                la, lb = self.truncated_lengths(len(qa), [len(qb)], rule)
+                got = self.prefix + qa[:la] + self.middle + qb[: lb[0]] + self.suffix
+                types = [0] * (len(self.prefix) + la + len(self.middle)) + [self.type_b] * (lb[0] + len(self.suffix))
+                if got != want["input_ids"] or (self.has_types and types != want["token_type_ids"]):
+                    good = False
+                    break
+            if good:
+                self.rule, self.ok = rule, True
+                return
+        self.why = "no known truncation rule reproduces the tokenizer"
+
+    # -- longest-first truncation in closed form -----------------------------------
+    def truncated_lengths(self, la: int, lb, rule: Optional[str] = None):
+        """Lengths kept of a query of `la` tokens paired with documents of `lb` tokens (sequence or
+        tensor) under longest-first truncation to max_length.  Returns (la' per document, lb')."""
+        rule = rule or self.rule
+        budget = self.max_length - len(self.prefix) - len(self.middle) - len(self.suffix)
+        is_t = torch.is_tensor(lb)
+        lbv = lb.to(torch.int64) if is_t else torch.as_tensor(list(lb), dtype=torch.int64)
+        lav = torch.full_like(lbv, int(la))
+        lav, lbv = self._longest_first(lav, lbv, budget, rule)
+        if is_t:
+            return lav, lbv
+        if len(lbv) == 1:
+            return int(lav[0]), [int(lbv[0])]
+        return [int(x) for x in lav], [int(x) for x in lbv]
+
+    @staticmethod
+    def _longest_first(la, lb, budget: int, rule: str):
+        """int64 tensors la, lb -> kept lengths.  Both known implementations first shorten the LONGER text
+        until the two are equal (or the excess is gone); they differ in how an odd remainder is split:
+          second_on_ties    transformers' python loop: one token at a time, from the second text on ties
+                            -> the second text loses ceil(e/2), the first floor(e/2);
+          longer_gets_odd   the tokenizers crate's closed form: floor(budget/2) for the originally shorter
+                            text (the FIRST on a tie), ceil(budget/2) for the originally longer one."""
+        first_longer = la > lb
+        e = (la + lb - budget).clamp(min=0)
+        c = torch.minimum(e, (la - lb).clamp(min=0))
+        la, e = la - c, e - c
+        c = torch.minimum(e, (lb - la).clamp(min=0))
+        lb, e = lb - c, e - c
+        if rule == "second_on_ties":
+            lb, la = lb - (e + 1) // 2, la - e // 2
+        else:
+            big, small = (e + 1) // 2, e // 2                     # what the two sides lose
+            la = la - torch.where(first_longer, small, big)
+            lb = lb - torch.where(first_longer, big, small)
+        return la.clamp(min=0), lb.clamp(min=0)
+
+    # -- document table ---------------------------------------------------------------
+    def add_documents(self, texts: Sequence[str]) -> None:
+        for t in texts:
+            ids = self.ids_of(t)
+            self._doc_len.append(len(ids))
+            self._doc_ids.append(ids[: self.max_length])
+        self._table = None
+
+    def __len__(self) -> int:
+        return len(self._doc_ids)
+
+    def table(self, device):
+        if self._table is None or self._table[0] != str(device):
+            n = len(self._doc_ids)
+            L = max(1, max((len(x) for x in self._doc_ids), default=1))
+            ids = np.full((n, L), self.pad, dtype=np.int32)
+            lens = np.zeros((n,), dtype=np.int32)
+            for i, x in enumerate(self._doc_ids):
+                ids[i, : len(x)] = x
+            lens[:] = self._doc_len
+            self._table = (str(device), torch.from_numpy(ids).to(device), torch.from_numpy(lens).to(device))
+        return self._table[1], self._table[2]
+
+    # -- batch tensors -----------------------------------------------------------------
+    def plan(self, q_ids: List[List[int]], pair_q, pair_slot, device):
+        """Everything that does not depend on the batch cut: per-pair kept lengths and total length.
+        pair_q / pair_slot: int64 tensors [P] (query number, document slot)."""
+        dtab, dlen = self.table(device)
+        Lq = max(1, min(self.max_length, max(len(x) for x in q_ids)))
+        qtab = torch.full((len(q_ids), Lq), self.pad, dtype=torch.int32)
+        for i, x in enumerate(q_ids):
+            x = x[: self.max_length]
+            qtab[i, : len(x)] = torch.as_tensor(x, dtype=torch.int32)
+        qtab = qtab.to(device)
+        qlen = torch.as_tensor([len(x) for x in q_ids], dtype=torch.int64, device=device)
+        budget = self.max_length - len(self.prefix) - len(self.middle) - len(self.suffix)
+        la, lb = self._longest_first(qlen[pair_q], dlen[pair_slot].to(torch.int64), budget, self.rule)
+        total = la + lb + (len(self.prefix) + len(self.middle) + len(self.suffix))
+        return {"qtab": qtab, "dtab": dtab, "la": la, "lb": lb, "total": total, "pair_q": pair_q, "pair_slot": pair_slot}
+
+    def batch(self, plan, sel, width: Optional[int] = None):
+        """input_ids / attention_mask / token_type_ids [len(sel), L] for the pairs `sel` (int64 tensor)."""
+        dev = plan["la"].device
+        la, lb = plan["la"][sel][:, None], plan["lb"][sel][:, None]
+        L = int(width) if width is not None else int(plan["total"][sel].max().item())
+        t = torch.arange(L, device=dev)[None, :]
+        npre, nmid, nsuf = len(self.prefix), len(self.middle), len(self.suffix)
+        a0 = npre
+        a1 = a0 + la
+        a2 = a1 + nmid
+        a3 = a2 + lb
+        a4 = a3 + nsuf
+        qrows = plan["qtab"][plan["pair_q"][sel]].to(torch.int64)
+        drows = plan["dtab"][plan["pair_slot"][sel]].to(torch.int64)
+        qpart = torch.gather(qrows, 1, (t - a0).clamp(0, qrows.shape[1] - 1).expand(len(sel), L))
+        dpart = torch.gather(drows, 1, (t - a2).clamp(0, drows.shape[1] - 1).expand(len(sel), L))
+
+        def const(vals, off):   # special tokens at positions off + i
+            if not vals:
+                return torch.zeros((1, 1), dtype=torch.int64, device=dev)
+            v = torch.as_tensor(vals, dtype=torch.int64, device=dev)
+            return v[(t - off).clamp(0, len(vals) - 1)]
+        ids = torch.full((len(sel), L), self.pad, dtype=torch.int64, device=dev)
+        ids = torch.where(t < a4, const(self.suffix, a3), ids)
+        ids = torch.where(t < a3, dpart, ids)
+        ids = torch.where(t < a2, const(self.middle, a1), ids)
+        ids = torch.where(t < a1, qpart, ids)
+        ids = torch.where(t < a0, const(self.prefix, 0), ids)
+        mask = (t < a4).to(torch.int64)
+        out = {"input_ids": ids, "attention_mask": mask}
+        if self.has_types:
+            out["token_type_ids"] = ((t >= a2) & (t < a4)).to(torch.int64) * self.type_b
+        return out
+
+
 # --------------------------------------------------------------------------- cross-encoder
 class CrossEncoderModel:
     """Stand-in for sentence_transformers.CrossEncoder (see module docstring)."""
@@ -510,11 +738,21 @@ class CrossEncoderModel:
             res[torch.as_tensor(np.ascontiguousarray(idx), device=self.device)] = lg.reshape(len(idx), -1)
         return res
 
-    def predict(self, sentences: Sequence[Sequence[str]], batch_size: int = 32,
-                show_progress_bar: bool = False, **_) -> np.ndarray:
-        lg = self.logits(sentences, batch_size=batch_size)
+    def activate(self, lg: torch.Tensor) -> torch.Tensor:
         if self.activation == "sigmoid":
             lg = torch.sigmoid(lg)
         if self.num_labels == 1:
             lg = lg.squeeze(-1)
-        return lg.cpu().numpy().astype(np.float32)
+        return lg
+
+    def predict(self, sentences: Sequence[Sequence[str]], batch_size: int = 32,
+                show_progress_bar: bool = False, **_) -> np.ndarray:
+        return self.activate(self.logits(sentences, batch_size=batch_size)).cpu().numpy().astype(np.float32)
+
+    @torch.no_grad()
+    def logits_from_ids(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Raw logits [P, num_labels] (float32) for already assembled id tensors on the model's device."""
+        if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
+            enc = {k: v for k, v in enc.items() if k != "token_type_ids"}
+        with _autocast(self.device, self.use_amp, self.amp_dtype):
+            return self.model(**enc).logits.float().reshape(enc["input_ids"].shape[0], -1)

@@ -100,6 +100,8 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
             s1.bm25_index.fit(s1.documents)
         if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
             self.stage2.index_documents(list(documents), 0)   # replicas keep the whole token store
+        if self.stage3 is not None and self.config.stage3_cache_document_tokens:
+            self.stage3.index_documents(list(documents), 0)
         self._install_data_parallel_scoring()
         self._indexed = True
 

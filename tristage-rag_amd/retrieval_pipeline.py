@@ -69,6 +69,9 @@ class PipelineConfig:
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
+    stage3_cache_document_tokens: bool = False  # tokenise every document once at add time; search_many then assembles
+                                                # the cross-encoder inputs from token ids on the GPU
+    stage3_many_batch_size: int = 1024       # pairs per cross-encoder forward in search_many
 
 
 # (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
@@ -167,7 +170,8 @@ class RetrievalPipeline:
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
                 max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
-                top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs))
+                top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs,
+                many_batch_size=c.stage3_many_batch_size))
             self.logger.info("Stage 3 initialized")
         except Exception as e:
             self.logger.error(f"Error initializing pipeline stages: {e}")
@@ -183,6 +187,8 @@ class RetrievalPipeline:
             self.stage1.add_documents(documents, metadata)
             if self.stage2 is not None and self.stage2.config.precompute_document_embeddings:
                 self.stage2.index_documents(list(documents), first_id)
+            if self.stage3 is not None and self.config.stage3_cache_document_tokens:
+                self.stage3.index_documents(list(documents), first_id)
         except Exception as e:
             self.logger.error(f"Error adding documents: {e}")
             raise
@@ -267,6 +273,9 @@ class RetrievalPipeline:
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
+            fast = self._search_many_arrays(queries, top_k)
+            if fast is not None:
+                return fast
             total_start = self._now()
             t = self._now()
             s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
@@ -277,6 +286,84 @@ class RetrievalPipeline:
         finally:
             if gc_was_on:
                 gc.enable()
+
+    def _search_many_arrays(self, queries: List[str], top_k: int) -> Optional[List[Dict[str, Any]]]:
+        """search_many with every stage on ARRAYS (the candidate sets never become Python records): stage 1
+        returns id / score matrices, stage 2 looks the candidates up in the resident token store and keeps the
+        best by one stable device sort, stage 3 assembles its (query, document) inputs from cached token ids on
+        the GPU; dictionaries are built only for what is returned (all three lists with
+        ``save_intermediate_results``, else the final top_k per query).  Same records as the per-record path
+        (tests).  None when a precondition is missing (HIP index on the device path, complete token store,
+        complete stage-3 id cache, at least stage1_top_k documents) — the caller then takes the record path."""
+        import torch
+        s1, s2, s3 = self.stage1, self.stage2, self.stage3
+        if not (getattr(s2, "token_store", None) is not None and len(s2.token_store)
+                and getattr(s3, "_pairs_usable", False) and hasattr(s1, "search_many_arrays")):
+            return None
+        timing = self.config.enable_timing
+        n = len(queries)
+
+        def tick():
+            if timing:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                return time.time()
+            return None
+        total_start = t = tick()
+        got = s1.search_many_arrays(queries, self.config.stage1_top_k)
+        if got is None:
+            return None
+        ids1, sc1 = got
+        dev = s2.token_store.data.device
+        ids1_dev = ids1 if torch.is_tensor(ids1) else torch.from_numpy(ids1).to(dev)
+        t1 = (tick() - t) / n if timing else None
+        t = tick() if timing else None
+        r2 = s2.rescore_arrays(queries, ids1_dev)
+        if r2 is None:
+            return None
+        pos2, sc2 = r2
+        ids2_dev = torch.gather(ids1_dev, 1, pos2)
+        t2 = (tick() - t) / n if timing else None
+        t = tick() if timing else None
+        r3 = s3.rerank_arrays(queries, ids2_dev)
+        if r3 is None:
+            return None
+        pos3, sc3 = r3
+        # one trip to the host for everything the records need
+        ids1_h = ids1_dev.cpu().numpy()
+        sc1_h = sc1.cpu().numpy() if torch.is_tensor(sc1) else sc1
+        pos2_h, sc2_h = pos2.cpu().numpy(), sc2.cpu().numpy()
+        pos3_h, sc3_h = pos3.cpu().numpy(), sc3.cpu().numpy()
+        t3 = (tick() - t) / n if timing else None
+        total = (time.time() - total_start) / n if timing else None
+        docs, meta = s1.documents, s1.doc_metadata
+        keep = self.config.save_intermediate_results
+
+        def rec1(q, j):
+            i = int(ids1_h[q, j])
+            s = float(sc1_h[q, j])
+            return {"doc_id": i, "document": docs[i], "score": s, "stage1_score": s, "metadata": meta[i],
+                    "stage": "stage1"}
+
+        def rec2(q, j):
+            r = rec1(q, int(pos2_h[q, j]))
+            r["stage2_score"] = float(sc2_h[q, j])
+            r["stage"] = "stage2"
+            return r
+
+        def rec3(q, j):
+            r = rec2(q, int(pos3_h[q, j]))
+            r["stage3_score"] = float(sc3_h[q, j])
+            r["stage"] = "stage3"
+            return r
+        out1 = [[rec1(q, j) for j in range(ids1_h.shape[1])] if keep else None for q in range(n)]
+        out2 = [[rec2(q, j) for j in range(pos2_h.shape[1])] if keep else None for q in range(n)]
+        out3 = [[rec3(q, j) for j in range(pos3_h.shape[1])] for q in range(n)]
+        if not keep:   # _assemble_many only tests the lists of a non-empty stage for truth
+            out1 = [[True]] * n
+            out2 = [[True]] * n
+        res = self._assemble_many(queries, top_k, out1, out2, out3, t1, t2, t3, total)
+        return res
 
     def _later_stages_many(self, queries, s1):
         """Stages 2 and 3 for several queries -> (stage-2 lists, stage-3 lists, per-query time shares)."""
@@ -338,6 +425,9 @@ class RetrievalPipeline:
                 from .stage2_rescorer import TokenStore
                 self.stage2.token_store, self.stage2._store_slot = TokenStore(), {}
                 self.stage2.index_documents(list(self.stage1.documents), 0)
+        if self.stage3 is not None and self.config.stage3_cache_document_tokens and self.stage1.documents:
+            self.stage3._pairs = None     # token ids are cheap to recompute: no file of their own
+            self.stage3.index_documents(list(self.stage1.documents), 0)
         self.logger.info(f"Pipeline index loaded from {index_path}")
 
     # -- introspection -----------------------------------------------------------

@@ -407,6 +407,66 @@ class Stage1Retriever:
             out.append(self._finish(query, dense, top_k))
         return out
 
+    def search_many_arrays(self, queries: Sequence[str], top_k: Optional[int] = None):
+        """Stage 1 for a query batch WITHOUT building result records: (ids int64 [B, k'], scores [B, k'])
+        as torch tensors on the index's device for the pure dense search, numpy arrays (float64 fused
+        scores) when BM25 fusion is on.  Row q, in order, is exactly what ``search_many`` would list for
+        query q.  None when the corpus holds fewer than top_k rows (the caller then uses ``search_many``,
+        which deals with padded results)."""
+        import torch
+        if self.faiss_index is None:
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        top_k = top_k or self.config.top_k_candidates
+        n = int(self.faiss_index.ntotal)
+        if top_k > n or n != len(self.documents):
+            return None
+        if self._device_path():
+            D, I = self.faiss_index.search(self._normalized_query_tensor(list(queries)), top_k)
+        else:
+            D, I = self.faiss_index.search(self._normalize_embeddings(self._encode_batch(list(queries))), top_k)
+            D, I = torch.as_tensor(D), torch.as_tensor(I)
+        if not (self.config.enable_bm25 and self.bm25_index is not None):
+            return I, D
+        ids, scores = I.cpu().numpy(), D.cpu().numpy()
+        out_i = np.empty((len(queries), top_k), dtype=np.int64)
+        out_s = np.empty((len(queries), top_k), dtype=np.float64)
+        for qi, query in enumerate(queries):
+            bm = self.bm25_index.search(query, self.config.bm25_top_k)
+            fi, fs = self._fuse_arrays(ids[qi], scores[qi], bm)
+            if len(fi) < top_k:
+                return None
+            out_i[qi], out_s[qi] = fi[:top_k], fs[:top_k]
+        return out_i, out_s
+
+    def _fuse_arrays(self, dense_ids: np.ndarray, dense_scores: np.ndarray, bm25_results):
+        """The fusion of _finish() on arrays: same float64 arithmetic, same order (descending fused score,
+        ties in first-seen order: dense list first, then the BM25-only documents) as the dictionary code of
+        _reciprocal_rank_fusion / _weighted_fusion (reference :326-366)."""
+        if not bm25_results:
+            return dense_ids, dense_scores.astype(np.float64)
+        b_ids = np.fromiter((i for i, _ in bm25_results), dtype=np.int64, count=len(bm25_results))
+        b_sc = np.fromiter((s for _, s in bm25_results), dtype=np.float64, count=len(bm25_results))
+        if self.config.fusion_method == "rrf":
+            d_part = 1.0 / (self.config.rrf_k + np.arange(len(dense_ids), dtype=np.float64) + 1)
+            b_part = 1.0 / (self.config.rrf_k + np.arange(len(b_ids), dtype=np.float64) + 1)
+        else:
+            d_sc = dense_scores.astype(np.float64)
+            if (len(d_sc) and d_sc.max() == 0.0) or b_sc.max() == 0.0:
+                raise ZeroDivisionError("float division by zero")   # what _weighted_fusion (and the reference) does
+            d_part = self.config.dense_weight * (d_sc / d_sc.max()) if len(d_sc) else d_sc
+            b_part = self.config.bm25_weight * (b_sc / b_sc.max())
+        # position of every BM25 document in the dense list (or -1)
+        order = np.argsort(dense_ids, kind="stable")
+        pos = np.searchsorted(dense_ids[order], b_ids)
+        pos = np.where(pos < len(order), pos, 0)
+        hit = dense_ids[order][pos] == b_ids if len(order) else np.zeros(len(b_ids), dtype=bool)
+        fused = d_part.copy()
+        fused[order[pos[hit]]] = fused[order[pos[hit]]] + b_part[hit]          # dense term first, then the BM25 term
+        all_ids = np.concatenate([dense_ids, b_ids[~hit]])
+        all_sc = np.concatenate([fused, (0.0 + b_part[~hit])])
+        rank = np.argsort(-all_sc, kind="stable")
+        return all_ids[rank], all_sc[rank]
+
     # -- persistence (reference :421-465; raw matrix + JSON instead of pickle + faiss file)
     def save_index(self, index_path: Optional[str] = None):
         if index_path is None:

@@ -359,6 +359,57 @@ class ColBERTScorer:
                   self.config.scoring_method).detach().cpu().tolist()
         return [[float(x) for x in flat[a:b]] for a, b in zip(c_off[:-1], c_off[1:])]
 
+    def _slot_table(self, device) -> Optional[torch.Tensor]:
+        """int64 [max doc id + 1]: pipeline doc id -> slot of the token store (-1 = not in the store)."""
+        n = len(self._store_slot)
+        cached = getattr(self, "_slot_tab", None)
+        if cached is not None and cached[0] == n and cached[1].device == torch.device(device):
+            return cached[1]
+        if not n:
+            return None
+        tab = torch.full((max(self._store_slot) + 1,), -1, dtype=torch.int64)
+        tab[torch.tensor(list(self._store_slot.keys()), dtype=torch.int64)] = torch.tensor(
+            list(self._store_slot.values()), dtype=torch.int64)
+        tab = tab.to(device)
+        self._slot_tab = (n, tab)
+        return tab
+
+    def rescore_arrays(self, queries: List[str], cand_ids: torch.Tensor):
+        """rescore_many on arrays: ``cand_ids`` int64 [B, C] (CUDA; every row the stage-1 candidates of that
+        query, in stage-1 order) -> (pos int64 [B, keep], scores float32 [B, keep]): the positions, in
+        stage-1 order, of the ``top_k_candidates`` best candidates by stage-2 score — the stable descending
+        sort of the reference (:293-297) — and their scores.  Everything stays on the GPU: one padded query
+        forward, one MaxSim launch over the resident token store, one sort.  None if a candidate is not in
+        the store."""
+        store = self.token_store
+        if not len(store) or cand_ids.dim() != 2:
+            return None
+        cand_ids = cand_ids.to(store.data.device)
+        tab = self._slot_table(cand_ids.device)
+        B, C = cand_ids.shape
+        if tab is None or int(cand_ids.max()) >= tab.numel() or int(cand_ids.min()) < 0:
+            return None
+        slots = tab[cand_ids.reshape(-1)]
+        if bool((slots < 0).any()):
+            return None
+        q_embs = self.encode_queries_batch(list(queries))
+        starts_all, lens_all = store.device_tables()
+        dt = store.data.dtype
+        q_off = [0]
+        for e in q_embs:
+            q_off.append(q_off[-1] + int(e.shape[0]))
+        c_off = [j * C for j in range(B + 1)]
+        q_packed = torch.cat([e.to(dt) for e in q_embs], 0).contiguous()
+        fn = self._maxsim_indexed_batch_fn
+        if fn is None:
+            from .index import maxsim_indexed_batch  # HIP kernel; raises without the library or a GPU
+            fn = maxsim_indexed_batch
+        flat = fn(q_packed, q_off, store.data, starts_all[slots], lens_all[slots], c_off, self.config.scoring_method)
+        sc = flat.to(cand_ids.device).view(B, C)
+        srt, pos = torch.sort(sc, dim=1, descending=True, stable=True)
+        keep = min(self.config.top_k_candidates, C)
+        return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
+
     def _keep_top(self, candidates: List[Dict[str, Any]], scores: List[float]) -> List[Dict[str, Any]]:
         scored = []
         for cand, s in zip(candidates, scores):

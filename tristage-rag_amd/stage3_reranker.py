@@ -176,6 +176,60 @@ class CrossEncoderReranker:
             out.append(reranked[: self.config.top_k_final])
         return out
 
+    # -- token-id level path (additive): documents tokenised once, pairs assembled on the GPU ------------
+    def index_documents(self, documents: List[str], first_doc_id: int) -> bool:
+        """Tokenise `documents` once and keep their ids for rerank_arrays(); document j gets pipeline id
+        first_doc_id + j.  False (and the id cache is dropped) when the tokenizer cannot be restated on the
+        device (encoders.PairAssembler probes it) or the ids are not consecutive from 0."""
+        from .encoders import CrossEncoderModel, PairAssembler
+        if not isinstance(self.model, CrossEncoderModel):
+            self._pairs = None
+            return False
+        pa = getattr(self, "_pairs", None)
+        if pa is None:
+            pa = PairAssembler(self.model.tokenizer, self.config.max_length)
+            self._pairs = pa
+        if not pa.ok or first_doc_id != len(pa):
+            self._pairs_usable = False
+            return False
+        pa.add_documents(documents)
+        self._pairs_usable = True
+        return True
+
+    def rerank_arrays(self, queries: List[str], doc_ids: torch.Tensor):
+        """rerank_many on arrays: doc_ids int64 [B, C] (CUDA; row q = the stage-2 list of query q, in stage-2
+        order) -> (pos int64 [B, keep], scores float64 [B, keep]): positions in stage-2 order of the
+        ``top_k_final`` best by stage-3 score (min-max normalised per query like reference :212-228, stable
+        descending sort :256-260).  The (query, document) inputs are assembled from cached token ids on the GPU
+        with the tokenizer's own truncation, run through the cross-encoder in length-sorted batches of
+        ``many_batch_size`` pairs.  None when the id cache does not cover the documents."""
+        pa = getattr(self, "_pairs", None)
+        if pa is None or not getattr(self, "_pairs_usable", False) or doc_ids.dim() != 2:
+            return None
+        B, C = doc_ids.shape
+        if B == 0 or C == 0 or int(doc_ids.max()) >= len(pa) or int(doc_ids.min()) < 0:
+            return None
+        dev = torch.device(self.model.device)
+        doc_ids = doc_ids.to(dev)
+        q_ids = [pa.ids_of(q) for q in queries]
+        pair_q = torch.arange(B, device=dev).repeat_interleave(C)
+        plan = pa.plan(q_ids, pair_q, doc_ids.reshape(-1), dev)
+        order = torch.argsort(plan["total"], descending=True, stable=True)
+        raw = torch.empty((B * C,), dtype=torch.float32, device=dev)
+        bs = max(self.config.batch_size, self.config.many_batch_size)
+        widths = plan["total"][order[::bs]].tolist()          # one host sync: the padded width of every batch
+        for j, s in enumerate(range(0, B * C, bs)):
+            sel = order[s: s + bs]
+            enc = pa.batch(plan, sel, width=int(widths[j]))
+            raw[sel] = self.model.activate(self.model.logits_from_ids(enc)).reshape(-1)
+        a = raw.view(B, C).to(torch.float64)
+        if self.config.normalize_scores:
+            mn, mx = a.min(dim=1, keepdim=True).values, a.max(dim=1, keepdim=True).values
+            a = torch.where(mx > mn, (a - mn) / (mx - mn), torch.zeros_like(a))
+        srt, pos = torch.sort(a, dim=1, descending=True, stable=True)
+        keep = min(self.config.top_k_final, C)
+        return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
+
     def batch_rerank(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]):
         if not queries or not candidates_list:
             return []
