@@ -68,6 +68,10 @@ enum ts_metric { TS_METRIC_INNER_PRODUCT = 0 };
                                    complete in memory when the call is made (not the output of
                                    work still pending on `stream`); results are ordered after
                                    the call on `stream` as usual.                             */
+#define TS_FLAG_CLASSIC 32u     /* search: take the five-launch filter path (query prep, sample scan,
+                                   thresholds, scan+filter, select) even where the one-launch scan
+                                   (query image, thresholds and scan+filter in ONE kernel) applies:
+                                   A/B measurements and tests; results are identical            */
 #define TS_FLAG_NORMALIZE 4u    /* add: L2-normalise rows x/(|x|+1e-8) on device first
                                    (reference src/stage1_retriever.py:285-288) */
 
@@ -135,9 +139,10 @@ int ts_index_set_id_offset(ts_index* h, int64_t offset);
  * used by save_index (reference src/stage1_retriever.py:421-441)            */
 int ts_index_reconstruct(ts_index* h, int64_t row0, int64_t n, float* out,
                          uint32_t flags, void* stream);
-/* counters of the last search on this handle: [0] path taken (0 dense,
- * 1 filter, 2 filter-then-dense fallback), [1] max candidates per query,
- * [2] sample rows, [3] sample rank m                                         */
+/* counters of the last search on this handle: [0] path taken (low 4 bits: 0 dense,
+ * 1 filter, 2 filter-then-dense fallback; +16 when the filter ran as the
+ * one-launch scan), [1] max candidates per query, [2] sample rows,
+ * [3] sample rank m                                                          */
 int ts_index_last_search_info(const ts_index* h, int64_t info[4]);
 
 /* Per-phase device timing of searches, measured with HIP events recorded on the

@@ -101,15 +101,15 @@ def _stage3_against_cpu(p, spec, query, s2_records, max_length, bf16_tol):
 
 
 def _run_config(tmp_path, models, n_docs, doc_words, n_single, n_many, s1k, s2k, topk, s3_max_length, s3_cpu_queries,
-                expect_path, bf16_tol):
+                expect_path, bf16_tol, build_batch=64):
     import torch
     from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
     docs, queries = _texts(n_docs, n_single + n_many, *doc_words)
     pc = PipelineConfig(stage1_model=models[0], stage2_model=models[1], stage3_model=models[2], device="cuda",
                         cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / "i"), log_file=str(tmp_path / "p.log"),
                         log_level="WARNING", stage1_top_k=s1k, stage2_top_k=s2k, stage3_top_k=topk,
-                        stage1_enable_bm25=False, stage1_index_dtype="bf16", stage1_batch_size=256,
-                        stage2_batch_size=64, stage3_batch_size=64, stage3_max_length=s3_max_length,
+                        stage1_enable_bm25=False, stage1_index_dtype="bf16", stage1_batch_size=max(256, build_batch),
+                        stage2_batch_size=build_batch, stage3_batch_size=64, stage3_max_length=s3_max_length,
                         stage2_precompute_document_embeddings=True, save_intermediate_results=True)
     p = RetrievalPipeline(config=pc)
     p.add_documents(docs)
@@ -178,6 +178,6 @@ def test_config4_pipeline_half_xlmr_large_stage3(tmp_path):
     n = 1 << 20
     p, _ = _run_config(tmp_path, ("random:bert:1024:2:16", "random:modernbert:768:2:12", "random:xlmr-large"),
                        n_docs=n, doc_words=(5, 11), n_single=2, n_many=4, s1k=1000, s2k=100, topk=10,
-                       s3_max_length=256, s3_cpu_queries=1, expect_path="filter", bf16_tol=4e-3)
+                       s3_max_length=256, s3_cpu_queries=1, expect_path="filter", bf16_tol=4e-3, build_batch=1024)
     assert p.stage1.embedding_dim == 1024 and p.stage3.model.model.config.num_hidden_layers == 24
     assert p.stage3.model.model.config.hidden_size == 1024 and p.stage3.config.max_length == 256

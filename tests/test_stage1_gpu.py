@@ -495,3 +495,56 @@ def test_k_equals_n_returns_every_row_in_canonical_order():
     assert all(sorted(r.tolist()) == list(range(1000)) for r in I)
     check_topk(D, I, corpus, queries, 1000)
     idx.close()
+
+
+@pytest.mark.parametrize("dtype,n,d,k,B,qdt", [("f16", 400_000, 128, 100, 64, "same"), ("bf16", 300_001, 256, 10, 7, "f32"),
+                                                ("f16", 1_000_000, 64, 1000, 64, "same"), ("f32", 500_000, 64, 50, 33, "same"),
+                                                ("f16", 262_144, 100, 257, 40, "f32"), ("bf16", 2_000_000, 96, 1000, 64, "same")])
+def test_one_launch_scan_equals_five_launch_path_and_oracle(torch_mod, dtype, n, d, k, B, qdt):
+    """The one-launch search (ts_fused.hip: query image, threshold histogram and scan+filter in ONE kernel) against
+    the five-launch filter path (bit-identical results: both are exact) and the oracle; synchronous,
+    asynchronous and pipelined submission; queries in the storage dtype and in float32."""
+    torch = torch_mod
+    corpus = make_corpus(n, d, seed=1234, dtype=dtype)
+    corpus[n // 3: n // 3 + 50] = corpus[5]                      # a few exact ties
+    queries = make_corpus(B, d, seed=4321, dtype=dtype)
+    idx = _index(d, dtype, torch.from_numpy(corpus).cuda())
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[dtype]
+    q = torch.from_numpy(queries).cuda()
+    q = q.float() if qdt == "f32" else q.to(tdt)
+    D, I = idx.search(q, k)
+    info = idx.last_search_info()
+    assert info["path"] == "filter" and info["one_launch"], info
+    assert k <= info["max_candidates"] <= 16384
+    Dc, Ic = idx.search(q, k, classic=True)
+    assert idx.last_search_info()["path"] == "filter" and not idx.last_search_info()["one_launch"]
+    assert torch.equal(I, Ic) and torch.equal(D, Dc)
+    check_topk(D.cpu().numpy()[:6], I.cpu().numpy()[:6], corpus, queries[:6], k)
+    for ready in (False, True):
+        outs = [idx.search(q, k, async_=True, inputs_ready=ready) for _ in range(7)]
+        assert idx.finish() == []
+        for Da, Ia in outs:
+            assert torch.equal(Ia, I) and torch.equal(Da, D)
+    Dh, Ih = idx.search(queries, k)                              # host pointers
+    assert np.array_equal(Ih, I.cpu().numpy())
+    idx.close()
+
+
+def test_one_launch_scan_falls_back_exactly_on_massive_ties(torch_mod):
+    torch = torch_mod
+    n, d, k = 600_000, 64, 300
+    corpus = make_corpus(n, d, seed=7, dtype="f16")
+    corpus[100_000:125_000] = corpus[3]                          # 25 000 exact ties: the candidate list overflows
+    queries = make_corpus(16, d, seed=8, dtype="f16")
+    queries[2] = corpus[3]
+    idx = _index(d, "f16", torch.from_numpy(corpus).cuda().half())
+    D, I = idx.search(torch.from_numpy(queries).cuda().half(), k)
+    info = idx.last_search_info()
+    assert info["path"] == "filter+dense-fallback" and info["one_launch"]
+    check_topk(D.cpu().numpy(), I.cpu().numpy(), corpus, queries, k)
+    q2 = torch.from_numpy(make_corpus(16, d, seed=9, dtype="f16")).cuda().half()
+    D2, I2 = idx.search(q2, k)                                   # the workspace is clean again afterwards
+    assert idx.last_search_info()["path"] == "filter" and idx.last_search_info()["one_launch"]
+    Dc, Ic = idx.search(q2, k, classic=True)
+    assert torch.equal(I2, Ic) and torch.equal(D2, Dc)
+    idx.close()

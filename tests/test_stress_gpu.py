@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from helpers import check_topk, make_corpus
+from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -128,13 +129,20 @@ def test_one_handle_many_host_threads():
     from tristage_rag_amd.index import FlatIPIndex
     d, n = 128, 200_000
     corpus = make_corpus(n, d, seed=91, dtype="f16")
-    corpus[30_000:50_000] = corpus[7]                       # massive exact ties
+    base = make_corpus(64, d, seed=92, dtype="f16")
+    q33 = make_corpus(33, d, seed=93, dtype="f16")
+    # 20 000 copies of one row that is (nearly) orthogonal to the 97 queries of the two filter-path jobs:
+    # for them it scores ~0 and never reaches a threshold, for the query equal to it it is 20 000 exact ties
+    qmat, _ = np.linalg.qr(np.concatenate([base, q33]).T.astype(np.float64))
+    v = np.random.default_rng(90).standard_normal(d)
+    v -= qmat @ (qmat.T @ v)
+    dup = oracle.quantize((v / np.linalg.norm(v)).astype(np.float32)[None, :], "f16")[0]
+    corpus[30_000:50_000] = dup                             # massive exact ties
     idx = FlatIPIndex(d, dtype="f16")
     idx.add(torch.from_numpy(corpus).cuda().half())
-    base = make_corpus(64, d, seed=92, dtype="f16")
     tie_q = base.copy()
-    tie_q[3] = corpus[7]                                    # this query's top 20 000 scores are equal
-    jobs = [dict(q=base, k=100), dict(q=make_corpus(33, d, seed=93, dtype="f16"), k=1000),
+    tie_q[3] = dup                                          # this query's top 20 000 scores are equal
+    jobs = [dict(q=base, k=100), dict(q=q33, k=1000),
             dict(q=tie_q, k=500), dict(q=make_corpus(64, d, seed=94, dtype="f16"), k=3000),
             dict(q=make_corpus(5, d, seed=95, dtype="f16"), k=10, host=True),
             dict(q=make_corpus(40, d, seed=96, dtype="f16"), scores=True)]

@@ -155,6 +155,36 @@ int ts_launch_qprep(const TsLayout& L, const void* q, int q_dtype, int nq,
                     int qh, uint4* qimg, uint32_t* cand_cnt, uint32_t* status,
                     hipStream_t stream);
 
+// ---------------------------------------------------------------- one-launch search (ts_fused.hip)
+// query preparation + threshold estimation + fused scan/filter in one kernel; see ts_fused.hip
+struct TsFusedArgs {
+  const uint4* corpus;
+  const void* queries;      // [nq, dim] rows of q_dtype (device)
+  int q_dtype;
+  int nq;
+  int64_t nblk, ntotal;
+  int scan_wgs, tau_wgs;    // workgroups streaming the corpus / estimating the thresholds
+  int sample_rounds;        // each wave's first rounds feed the threshold histogram
+  int spill_rounds;         // rounds a wave may park before it has to wait for the thresholds
+  int64_t sample_stride;    // sample item s is row block s*sample_stride
+  uint32_t m;               // wanted rank among the sample's 16-row group maxima
+  uint32_t expect;          // histogram entries per query of a complete sample
+  uint32_t gen;             // generation tag of the launch (non-zero, unique per workspace set)
+  uint32_t arrive_goal;     // value of *arrive once every sample wave has reported
+  uint32_t wait_iters;      // bound of every in-kernel spin
+  uint32_t* hist;           // [64][16384] uint32, all-zero between launches
+  uint32_t* arrive;
+  unsigned long long* tau64;   // [64]
+  float* spill;             // ts_fused_spill_bytes()
+  uint32_t* cand_cnt;       // [64], zero at launch
+  float* cand_score;
+  int32_t* cand_id;
+  uint32_t cand_cap;
+};
+size_t ts_fused_hist_bytes();
+size_t ts_fused_spill_bytes(int scan_wgs, int spill_rounds);
+int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t stream);
+
 // ---------------------------------------------------------------- select
 enum { SEL_DENSE = 0, SEL_PAIRS32 = 1, SEL_MERGE64 = 2 };
 
@@ -185,6 +215,8 @@ struct SelParams {
   uint32_t* status;        // optional device status word (TS_STATUS_* bits are OR-ed in)
   uint32_t* host_report;   // optional, device view of pinned host memory:
                            // [q] = candidate count of query q, [64] |= status bits
+  uint32_t* clear_counts;  // optional: n_per_q is given back as zeros (the one-launch search has no
+                           // preparation kernel that would clear it)
 };
 
 int ts_launch_select(const SelParams& p, int nq, hipStream_t stream);

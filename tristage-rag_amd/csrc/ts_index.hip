@@ -107,6 +107,12 @@ struct ts_index {
   struct WSet {
     DevBuf qimg, small, cand_score, cand_id, sample;
     DevBuf dense, list_score, list_id;   // the dense path's score chunk and per-chunk lists
+    DevBuf hist, spill;                  // one-launch search (ts_fused.hip): threshold histogram, parked score tiles
+    uint32_t gen = 0;                    // generation tag of the last one-launch search on this set
+    uint32_t arrive_total = 0;           // running goal of the set's arrival hint counter
+    bool hist_dirty = false;             // a launch may have left entries behind: cleared before the next one
+    unsigned long long* tau64() { return (unsigned long long*)((char*)small.p + 1024); }
+    uint32_t* arrive() { return (uint32_t*)((char*)small.p + 2048); }
     hipEvent_t ev_pro = nullptr, ev_scan = nullptr, ev_sel = nullptr, ev_in = nullptr;  // timing disabled
     bool used = false;  // ev_sel has been recorded at least once
     bool busy = false;  // held by a search that is being enqueued / a synchronous search in flight (h->mu)
@@ -133,7 +139,7 @@ struct ts_index {
   uint32_t* host_status_dev = nullptr;  // device view of host_status
   // asynchronous searches (TS_FLAG_ASYNC): each pass reports into its own slot of
   // the mapped host ring; ts_index_finish() syncs once and inspects them all
-  struct Pending { int64_t ticket; int slot; int nq; uint32_t S; uint32_t m; hipEvent_t e0, e1; };
+  struct Pending { int64_t ticket; int slot; int nq; uint32_t S; uint32_t m; hipEvent_t e0, e1; int set; };
   Pending pending[TS_ASYNC_SLOTS];
   int npending = 0;
   uint64_t slot_next = 0;
@@ -235,6 +241,7 @@ extern "C" int ts_index_create(int32_t dim, int32_t storage_dtype, int32_t metri
   int st = TS_OK;
   for (ts_index::WSet& w : h->ws) {
     if (st == TS_OK) st = ensure(w.small, 4096);
+    if (st == TS_OK && hipMemset(w.small.p, 0, 4096) != hipSuccess) { ts_set_error("hipMemset failed"); st = TS_ERR_HIP; }
     if (st == TS_OK) st = ensure(w.qimg, (size_t)L.kg * 2 * 1024);
     if (st == TS_OK && (hipEventCreateWithFlags(&w.ev_pro, hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&w.ev_scan, hipEventDisableTiming) != hipSuccess ||
@@ -266,7 +273,8 @@ extern "C" int ts_index_destroy(ts_index* h) {
   DevBuf* bufs[] = {&h->stage, &h->den, &h->qstage, &h->out_s, &h->out_i};
   for (DevBuf* b : bufs) release(*b);
   for (ts_index::WSet& w : h->ws) {
-    DevBuf* wb[] = {&w.qimg, &w.small, &w.cand_score, &w.cand_id, &w.sample, &w.dense, &w.list_score, &w.list_id};
+    DevBuf* wb[] = {&w.qimg, &w.small, &w.cand_score, &w.cand_id, &w.sample, &w.dense, &w.list_score, &w.list_id,
+                    &w.hist, &w.spill};
     for (DevBuf* b : wb) release(*b);
     hipEvent_t evs[] = {w.ev_pro, w.ev_scan, w.ev_sel, w.ev_in};
     for (hipEvent_t e : evs)
@@ -482,6 +490,48 @@ static int ensure_streams(ts_index* h) {
 // for Sel: P of the NEXT search and Sel of the PREVIOUS one then run beside the current S, which
 // leaves an eighth of the CUs free and is HBM-bound anyway.  Passes alternate between two
 // workspace sets; a set is reused only after the Sel that last read it (its ev_sel).
+// ---- geometry of the one-launch search
+struct FusedPlan {
+  int scan_wgs, tau_wgs, sample_rounds, spill_rounds;
+  int64_t sample_stride, sample_rows;
+  uint32_t m, expect, sample_waves;
+};
+static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool pipe, FusedPlan* fp) {
+  // pipelined: the scan leaves a quarter of the CUs to its neighbours' select (64 workgroups that cannot
+  // share a CU with a scan workgroup: they always fit, whatever is placed first) and to the exchange;
+  // otherwise an eighth (the kernel is HBM-bound: 224 CUs stream as fast as 256, tools/cus.sh)
+  int scan_wgs = pipe ? h->num_cus - h->num_cus / 4 : h->num_cus - h->num_cus / 8;
+#ifdef TS_TUNING
+  static const int dbg_cus = getenv("TS_SCAN_CUS") ? atoi(getenv("TS_SCAN_CUS")) : 0;
+  if (dbg_cus > 0) scan_wgs = dbg_cus;
+#endif
+  if (scan_wgs < 1) return false;
+  const int tau_wgs = std::max(1, std::min(32, h->num_cus - scan_wgs));
+  const int64_t nwaves = (int64_t)scan_wgs * 8;
+  if (nblk < nwaves) return false;                         // fewer row blocks than waves: a latency-bound corpus
+  const int64_t want_rows = std::max(kMinSampleRows, N / kSampleDiv);
+  int64_t R = (want_rows + nwaves * TS_ROWS_PER_BLOCK - 1) / (nwaves * TS_ROWS_PER_BLOCK);
+  R = std::max<int64_t>(1, std::min<int64_t>(R, 16));
+  const int64_t n_sample = std::min(nblk, R * nwaves);
+  const int64_t stride = std::max<int64_t>(1, nblk / n_sample);
+  const int64_t rows = n_sample * TS_ROWS_PER_BLOCK;
+  const int64_t oversample = k > 1024 ? 3 : kOversample;
+  uint32_t m = (uint32_t)((oversample * (int64_t)k * rows + N - 1) / N);
+  m = std::max(m, kMinSampleRank);
+  const uint32_t expect = (uint32_t)(2 * n_sample);        // one group maximum per (wave, round, lane half)
+  if ((uint64_t)m * 4 > expect) return false;              // group maxima would no longer stand in for scores
+  fp->scan_wgs = scan_wgs;
+  fp->tau_wgs = tau_wgs;
+  fp->sample_rounds = (int)R;
+  fp->spill_rounds = (int)R + 4;
+  fp->sample_stride = stride;
+  fp->sample_rows = rows;
+  fp->m = m;
+  fp->expect = expect;
+  fp->sample_waves = (uint32_t)std::min(nwaves, n_sample);
+  return true;
+}
+
 // ---- the set pool and the report-slot ring (both under h->mu)
 static ts_index::WSet* acquire_set(ts_index* h) {
   std::unique_lock<std::mutex> lk(h->mu);
@@ -550,7 +600,12 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   const bool async = (flags & TS_FLAG_ASYNC) != 0;
   const bool pipe = filter && async && (flags & TS_FLAG_PIPELINE) != 0;
   if (pipe) TS_CHECK(ensure_streams(h));
-  hipStream_t sP = pipe ? h->s_pro : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
+  // ---- one-launch search (ts_fused.hip) whenever its threshold estimate is valid: the sample's 16-row
+  // group maxima stand in for the scores, which holds while the wanted rank is far below the group count
+  FusedPlan fp{};
+  const bool fused = filter && !(flags & TS_FLAG_CLASSIC) && plan_fused(h, N, nblk, k, pipe, &fp);
+  // (the one-launch search has no preparation phase: what remains of "P" rides on the scan stream)
+  hipStream_t sP = pipe ? (fused ? h->s_scan : h->s_pro) : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
   // the set may still be in use on the GPU by the (asynchronous) search that had it last, possibly
   // on another stream
   if (W.used) TS_HIP(hipStreamWaitEvent(sP, W.ev_sel, 0));
@@ -562,7 +617,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   h->prof_now = h->profiling && (h->prof_seq++ % (uint64_t)h->prof_every == 0);
   h->prof_scan_only = async;
   prof_mark(h, 0, sP);
-  TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), sP));
+  if (!fused) TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), sP));
   if (!filter) {
     set_info(h, 0, 0, 0, 0);
     prof_mark(h, 5, s);
@@ -575,7 +630,56 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     prof_collect(h);
     return TS_OK;
   }
-  // ---- filter path: sample -> thresholds -> fused scan+filter -> select
+  int64_t S = 0;
+  uint32_t m = 0;
+  TS_CHECK(ensure(W.cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
+  TS_CHECK(ensure(W.cand_id, (size_t)TS_MAX_Q * kCandCap * 4));
+  if (fused) {
+    // ---- ONE launch: query image, thresholds and scan+filter (see ts_fused.hip)
+    if (!W.hist.p) {
+      TS_CHECK(ensure(W.hist, ts_fused_hist_bytes()));
+      W.hist_dirty = true;
+    }
+    TS_CHECK(ensure(W.spill, ts_fused_spill_bytes(fp.scan_wgs, fp.spill_rounds)));
+    if (W.hist_dirty) {
+      TS_HIP(hipMemsetAsync(W.hist.p, 0, ts_fused_hist_bytes(), sS));
+      TS_HIP(hipMemsetAsync(W.cand_cnt(), 0, 256, sS));
+      W.hist_dirty = false;
+    }
+    if (++W.gen == 0) W.gen = 1;
+    W.arrive_total += fp.sample_waves;
+    TsFusedArgs a{};
+    a.corpus = h->corpus;
+    a.queries = dq;
+    a.q_dtype = q_dtype;
+    a.nq = nq;
+    a.nblk = nblk;
+    a.ntotal = N;
+    a.scan_wgs = fp.scan_wgs;
+    a.tau_wgs = fp.tau_wgs;
+    a.sample_rounds = fp.sample_rounds;
+    a.spill_rounds = fp.spill_rounds;
+    a.sample_stride = fp.sample_stride;
+    a.m = fp.m;
+    a.expect = fp.expect;
+    a.gen = W.gen;
+    a.arrive_goal = W.arrive_total;
+    a.wait_iters = 40000;
+    a.hist = (uint32_t*)W.hist.p;
+    a.arrive = W.arrive();
+    a.tau64 = W.tau64();
+    a.spill = (float*)W.spill.p;
+    a.cand_cnt = W.cand_cnt();
+    a.cand_score = (float*)W.cand_score.p;
+    a.cand_id = (int32_t*)W.cand_id.p;
+    a.cand_cap = kCandCap;
+    prof_mark(h, 3, sS);
+    TS_CHECK(ts_launch_fused(h->L, qh, a, sS));
+    prof_mark(h, 4, sS);
+    S = fp.sample_rows;
+    m = fp.m;
+  } else {
+  // ---- five launches: sample -> thresholds -> scan+filter (-> select below)
   int64_t nsb = std::max(kMinSampleRows, N / kSampleDiv) / TS_ROWS_PER_BLOCK;
   // one sample block per scan wave (8 waves per CU): a ragged last round would
   // make the short sample scan ~1.7x longer than it has to be
@@ -583,15 +687,13 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   if (nsb > round) nsb -= nsb % round;
   nsb = std::min(nsb, nblk);
   const int64_t sstride = nblk / nsb;
-  const int64_t S = nsb * TS_ROWS_PER_BLOCK;
+  S = nsb * TS_ROWS_PER_BLOCK;
   // expected survivors per query ~ oversample * k; 3x for large k keeps the worst query of a
   // batch (about 1.5x the mean) well inside the 16384 candidate slots
   const int64_t oversample = k > 1024 ? 3 : kOversample;
-  uint32_t m = (uint32_t)((oversample * (int64_t)k * S + N - 1) / N);
+  m = (uint32_t)((oversample * (int64_t)k * S + N - 1) / N);
   m = std::max(m, kMinSampleRank);
   TS_CHECK(ensure(W.sample, (size_t)nq * S * 4));
-  TS_CHECK(ensure(W.cand_score, (size_t)TS_MAX_Q * kCandCap * 4));
-  TS_CHECK(ensure(W.cand_id, (size_t)TS_MAX_Q * kCandCap * 4));
 
   ScanParams sp{};
   sp.corpus = h->corpus;
@@ -639,6 +741,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   prof_mark(h, 3, sS);
   TS_CHECK(ts_launch_scan(h->L, SCAN_FILTER, qh, sp, scan_cus, sS));
   prof_mark(h, 4, sS);
+  }  // five launches
   if (pipe) {
     TS_HIP(hipEventRecord(W.ev_scan, sS));
     TS_HIP(hipStreamWaitEvent(sL, W.ev_scan, 0));
@@ -655,7 +758,8 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
 #else
     constexpr int head_us = kHeadStartUs;
 #endif
-    if (head_us > 0) hipLaunchKernelGGL(head_start_kernel, dim3(1), dim3(64), 0, sL, head_us, 4096);
+    // (the one-launch scan occupies 3/4 of the CUs: the select's 64 workgroups always fit beside it)
+    if (head_us > 0 && !fused) hipLaunchKernelGGL(head_start_kernel, dim3(1), dim3(64), 0, sL, head_us, 4096);
   }
   // (4) exact top-k of the candidates; verifies that >= k of them exist
   SelParams p{};
@@ -672,6 +776,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   p.out_stride = k;
   p.id_offset = h->id_offset;
   p.status = W.status();
+  p.clear_counts = fused ? W.cand_cnt() : nullptr;   // (the five-launch path clears them in its query prep)
   // the select kernel reports the candidate counts and the status word straight
   // into mapped host memory: no copy kernel between it and the sync; every search in flight
   // has its own slot of the ring
@@ -693,6 +798,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     ts_index::Pending& pe = h->pending[h->npending];
     pe.ticket = h->next_ticket; pe.slot = slot; pe.nq = nq; pe.S = (uint32_t)S; pe.m = m;
     pe.e0 = pe.e1 = nullptr;
+    pe.set = fused ? (int)(&W - h->ws) : -1;
     if (h->profiling && h->prof_now && h->nev == 2) {  // the scan+filter interval of this pass
       pe.e0 = h->ev[0]; pe.e1 = h->ev[1];
       // hand the two events over and give the handle fresh ones
@@ -718,10 +824,14 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   for (int i = 0; i < nq; ++i) maxc = std::max(maxc, rep[i]);
   const bool redo = rep[64] != 0;
   free_slot(h, slot);
-  set_info(h, redo ? 2 : 1, maxc, S, m);
+  set_info(h, (redo ? 2 : 1) | (fused ? 16 : 0), maxc, S, m);
   if (redo) {
     // a threshold was too high (fewer than k survivors) or too low (candidate
     // list overflowed, e.g. massive score ties): redo this pass exactly.
+    if (fused) {   // (no prepared query image yet; a threshold workgroup that gave up may have left entries behind)
+      W.hist_dirty = true;
+      TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), s));
+    }
     prof_mark(h, 5, s);
     TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
     prof_mark(h, -1, s);
@@ -868,6 +978,7 @@ extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_ticket
     const uint32_t* rep = h->host_status + (size_t)pe.slot * TS_SLOT_WORDS;
     for (int q = 0; q < pe.nq; ++q) maxc = std::max(maxc, rep[q]);
     if (rep[64] != 0) {
+      if (pe.set >= 0 && pe.set < TS_NSETS) h->ws[pe.set].hist_dirty = true;
       if (nf == 0 || failed_tickets[nf - 1] != pe.ticket) {
         if (nf < max_failed) failed_tickets[nf] = pe.ticket;
         ++nf;
@@ -879,7 +990,7 @@ extern "C" int ts_index_finish(ts_index* h, void* stream, int64_t* failed_ticket
       (void)hipEventDestroy(pe.e0);
       (void)hipEventDestroy(pe.e1);
     }
-    h->info[0] = 1; h->info[2] = pe.S; h->info[3] = pe.m;
+    h->info[0] = 1 | (pe.set >= 0 ? 16 : 0); h->info[2] = pe.S; h->info[3] = pe.m;
     h->slot_busy[pe.slot] = false;
   }
   if (h->npending) h->info[1] = maxc;

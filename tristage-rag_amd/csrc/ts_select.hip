@@ -202,7 +202,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelParams p, uint32
   if (p.n_per_q) {
     const uint32_t c = p.n_per_q[q];
     n = c < p.n_cap ? c : p.n_cap;
+    __syncthreads();   // every thread has read the count before it is given back
     if (tid == 0) {
+      if (p.clear_counts) p.clear_counts[q] = 0u;
       uint32_t st = 0;
       if (c > p.n_cap) st |= TS_STATUS_OVERFLOW;
       if (c < p.need) st |= TS_STATUS_SHORT;

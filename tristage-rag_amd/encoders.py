@@ -422,8 +422,8 @@ class SentenceEncoder:
         single = isinstance(sentences, str)
         texts = [sentences] if single else list(sentences)
         order = np.argsort([-len(t) for t in texts], kind="stable")  # length-sorted batches
-        out: List[Optional[torch.Tensor]] = [None] * len(texts)
-        use_amp = torch.is_autocast_enabled() or False
+        res = torch.zeros((len(texts), self.get_sentence_embedding_dimension()), dtype=torch.float32,
+                          device=self.device)
         for s in range(0, len(texts), batch_size):
             idx = order[s:s + batch_size]
             enc = self.tokenizer([texts[i] for i in idx], truncation=True, padding=True,
@@ -444,10 +444,8 @@ class SentenceEncoder:
                 emb = d(emb)
             if self.normalize or normalize_embeddings:
                 emb = F.normalize(emb, p=2, dim=1)
-            for j, i in enumerate(idx):
-                out[i] = emb[j]
-        del use_amp
-        res = torch.stack(out).float() if out else torch.zeros((0, self.get_sentence_embedding_dimension()))
+            # back into the caller's order: one scatter per batch (not one tiny copy per text)
+            res[torch.as_tensor(np.ascontiguousarray(idx), device=res.device)] = emb.float()
         if single:
             res = res[0]
         if convert_to_tensor:

@@ -130,7 +130,7 @@ class FlatIPIndex:
         return None
 
     def search(self, q, k: int, exact_dense: bool = False, async_: bool = False, out=None,
-               inputs_ready: bool = False):
+               inputs_ready: bool = False, classic: bool = False):
         """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
         numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out.
 
@@ -147,6 +147,8 @@ class FlatIPIndex:
         if k <= 0:
             raise ValueError("k must be positive")
         flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
+        if classic:   # the five-launch filter path even where the one-launch scan applies (A/B, tests)
+            flags |= _lib.TS_FLAG_CLASSIC
         if async_:
             if not (_is_tensor(q) and q.is_cuda):
                 raise ValueError("async_ search needs a CUDA tensor")
@@ -280,7 +282,8 @@ class FlatIPIndex:
     def last_search_info(self) -> dict:
         arr = (ctypes.c_int64 * 4)()
         _lib.check(self._lib.ts_index_last_search_info(self._h, arr))
-        return {"path": ("dense", "filter", "filter+dense-fallback")[arr[0]],
+        return {"path": ("dense", "filter", "filter+dense-fallback")[arr[0] & 15],
+                "one_launch": bool(arr[0] & 16),   # query image + thresholds + scan+filter in ONE kernel
                 "max_candidates": int(arr[1]), "sample_rows": int(arr[2]),
                 "sample_rank": int(arr[3])}
 

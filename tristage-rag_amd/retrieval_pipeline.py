@@ -69,6 +69,7 @@ class PipelineConfig:
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
+    stage2_token_store_dtype: str = "auto"   # "auto": bf16 under AMP, else the encoder's output type; or bf16 | f16 | f32
     stage3_cache_document_tokens: bool = False  # tokenise every document once at add time; search_many then assembles
                                                 # the cross-encoder inputs from token ids on the GPU
     stage3_many_batch_size: int = 1024       # pairs per cross-encoder forward in search_many
@@ -165,6 +166,7 @@ class RetrievalPipeline:
                 scoring_method=c.stage2_scoring_method,
                 cache_document_embeddings=c.stage2_cache_document_embeddings,
                 precompute_document_embeddings=c.stage2_precompute_document_embeddings,
+                token_store_dtype=c.stage2_token_store_dtype,
                 use_hip_graph=c.use_hip_graphs))
             self.logger.info("Stage 2 initialized")
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(

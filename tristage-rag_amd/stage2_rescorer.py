@@ -40,6 +40,9 @@ class Stage2Config:
     # additive
     cache_document_embeddings: bool = False      # memoise token matrices per document text
     precompute_document_embeddings: bool = False  # resident token store filled at add time
+    token_store_dtype: str = "auto"               # storage type of the resident token store: "auto" = bf16 when the
+                                                  # encoder runs under AMP (its last LayerNorm hands back fp32 even
+                                                  # then), else the encoder's own output type; or "bf16" | "f16" | "f32"
     use_hip_graph: bool = False                   # replay the batch-1 query forward from a HIP graph
 
 
@@ -77,6 +80,26 @@ class TokenStore:
             self.starts.append(self.rows)
             self.lens.append(n)
             self.rows += n
+        self._starts_dev = None
+
+    def append_packed(self, rows: torch.Tensor, lens: List[int]) -> None:
+        """`rows` [sum(lens), H]: the token rows of len(lens) documents, back to back."""
+        add = int(rows.shape[0])
+        if not lens:
+            return
+        if self.data is None or self.rows + add > self.data.shape[0]:
+            cap = max(self.rows + add, int(1.5 * (self.data.shape[0] if self.data is not None else 0)), 1024)
+            new = torch.empty((cap, int(rows.shape[1])), dtype=rows.dtype, device=rows.device)
+            if self.data is not None and self.rows:
+                new[: self.rows].copy_(self.data[: self.rows])
+            self.data = new
+        self.data[self.rows: self.rows + add].copy_(rows)
+        at = self.rows
+        for n in lens:
+            self.starts.append(at)
+            self.lens.append(int(n))
+            at += int(n)
+        self.rows += add
         self._starts_dev = None
 
     def device_tables(self):
@@ -236,15 +259,29 @@ class ColBERTScorer:
         scores = fn(q, packed, off.to(q.device), mode or self.config.scoring_method)
         return [float(x) for x in scores.detach().cpu().tolist()]
 
+    def store_dtype(self) -> Optional[torch.dtype]:
+        name = self.config.token_store_dtype
+        if name == "auto":
+            return torch.bfloat16 if self.use_amp else None
+        return {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[name]
+
     def index_documents(self, documents: List[str], first_doc_id: int) -> None:
         """Encode `documents` once and keep their token matrices on the GPU; document j
-        gets pipeline id first_doc_id + j (the doc_id stage 1 reports)."""
+        gets pipeline id first_doc_id + j (the doc_id stage 1 reports).  Same tokenisation, padding
+        and forward as encode_documents_batch (reference :207-242); the valid rows of a batch go
+        into the store with ONE masked copy (row-major mask order = document order)."""
         bs = max(self.config.batch_size, 1)
-        for s in range(0, len(documents), 8 * bs):
-            chunk = documents[s: s + 8 * bs]
-            mats = self.encode_documents_batch(chunk)
+        dt = self.store_dtype()
+        for s in range(0, len(documents), bs):
+            chunk = documents[s: s + bs]
+            enc = self._tokenize_batch(list(chunk))
+            hidden = self._forward(enc)
+            mask = enc["attention_mask"].bool()
+            rows = hidden[mask]                                  # [sum(lens), H]
+            if dt is not None and rows.dtype != dt:
+                rows = rows.to(dt)
             base = len(self.token_store)
-            self.token_store.append([m.contiguous() for m in mats])
+            self.token_store.append_packed(rows, mask.sum(dim=1).tolist())
             for j in range(len(chunk)):
                 self._store_slot[first_doc_id + s + j] = base + j
 
