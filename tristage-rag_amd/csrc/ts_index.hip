@@ -776,7 +776,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   p.out_stride = k;
   p.id_offset = h->id_offset;
   p.status = W.status();
-  p.clear_counts = fused ? W.cand_cnt() : nullptr;   // (the five-launch path clears them in its query prep)
+  p.clear_counts = W.cand_cnt();   // counts go back to zero: the one-launch search has no preparation kernel to do it
   // the select kernel reports the candidate counts and the status word straight
   // into mapped host memory: no copy kernel between it and the sync; every search in flight
   // has its own slot of the ring
