@@ -61,6 +61,9 @@ def parse_args():
                          "(the NULL stream synchronises implicitly with every blocking stream of the process: "
                          "0.332 -> 0.324 ms per batch at 1.25 M rows per rank), the NULL stream otherwise")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--classic", action="store_true",
+                    help="A/B: the five-launch filter path (query prep, sample scan, thresholds, scan+filter, select) "
+                         "instead of the one-launch scan")
     ap.add_argument("--step-events", choices=["auto", "on", "off"], default="auto",
                     help="one HIP event per timed step on the submitting stream -> ms_per_step_min/max "
                          "(a few microseconds each in-stream).  auto: on for N=1, off for N>1")
@@ -204,6 +207,7 @@ def main():
     # ---- build the (sharded) index; nothing here is timed
     lo, hi = shard_bounds(args.rows, world, rank)
     local = FlatIPIndex(args.dim, dtype=args.dtype, device=local_rank)
+    local.classic_filter = args.classic or bool(os.environ.get("TS_BENCH_CLASSIC"))
     local.reserve(max(hi - lo, 1))
     blk = 500_000
     for r0 in range(lo, hi, blk):
@@ -280,7 +284,8 @@ def main():
     shard_rows = hi - lo
     alg_bytes = float(-(-shard_rows // 32) * 32) * dpad * esize
     scan_ms, scan_cnt = tm["filter_scan"] if tm["filter_scan"][1] else tm["dense"]
-    kernel = "scan_kernel<filter>" if tm["filter_scan"][1] else "dense path (scan+select)"
+    kernel = (("fused_kernel (query image + thresholds + scan+filter)" if info.get("one_launch") else "scan_kernel<filter>")
+              if tm["filter_scan"][1] else "dense path (scan+select)")
     roof = None
     if scan_cnt:
         avg_ms = scan_ms / scan_cnt
@@ -335,7 +340,9 @@ def main():
                                      ("batches enqueued back to back (async" + ("" if not pipeline else ", pipelined: prep/select of "
                                       "neighbouring batches overlap the scan") + "), verified by finish() in the timed region"),
                        "sync_batch_latency_ms": round(sync_latency_ms, 4),
-                       "search_path": info["path"], "max_candidates_per_query": info["max_candidates"],
+                       "search_path": info["path"] + (" (one launch: query image + thresholds + scan+filter)"
+                                                      if info.get("one_launch") else ""),
+                       "max_candidates_per_query": info["max_candidates"],
                        "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]}},
             "roofline": roof,
             "secondary": enc_leg,

@@ -46,9 +46,16 @@ class Capture:
 def _texts(n_docs, n_queries, lo, hi, seed=0):
     rng = np.random.default_rng(seed)
     vocab = [f"w{i}" for i in range(5000)]
-    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(lo, hi)))) for _ in range(n_docs)]
-    queries = [" ".join(rng.choice(vocab, size=int(rng.integers(4, 16)))) for _ in range(n_queries)]
-    return docs, queries
+
+    def make(n, a, b):   # (one draw of all word indices: a million rng.choice calls on a list take minutes)
+        lens = rng.integers(a, b, size=n)
+        words = rng.integers(0, len(vocab), size=int(lens.sum())).tolist()
+        out, at = [], 0
+        for m in lens.tolist():
+            out.append(" ".join(vocab[i] for i in words[at: at + m]))
+            at += m
+        return out
+    return make(n_docs, lo, hi), make(n_queries, 4, 16)
 
 
 def _check_stage1(records, stored, q_used, k, dtype="bf16"):

@@ -40,6 +40,8 @@ if __name__ == "__main__":
            rate("random:modernbert", "base", 64, 128),       # stage-2 token store build (ModernBERT-base shape)
            rate("random:modernbert", "base", 1, 16),         # stage-2 query forward, batch 1
            rate("random:minilm", "seqcls", 1024, 168),       # stage-3 rerank_many forward
-           rate("random:minilm", "seqcls", 128, 192)]        # stage-3 per-query forward (graph bucket)
+           rate("random:minilm", "seqcls", 128, 192),        # stage-3 per-query forward (graph bucket)
+           rate("random:xlmr-large", "seqcls", 100, 256, reps=5),   # configs[4] stage 3: bge-reranker-large shape, one query's 100 pairs
+           rate("random:xlmr-large", "seqcls", 1024, 64, reps=3)]   # the same model on search_many-sized batches of short pairs
     for o in out:
         print(json.dumps(o))

@@ -164,15 +164,15 @@ struct TsFusedArgs {
   int nq;
   int64_t nblk, ntotal;
   int scan_wgs, tau_wgs;    // workgroups streaming the corpus / estimating the thresholds
-  int sample_rounds;        // each wave's first rounds feed the threshold histogram
+  int64_t n_sample;         // row blocks that feed the threshold sample: sample item s is block s*sample_stride
   int spill_rounds;         // rounds a wave may park before it has to wait for the thresholds
   int64_t sample_stride;    // sample item s is row block s*sample_stride
   uint32_t m;               // wanted rank among the sample's 16-row group maxima
-  uint32_t expect;          // histogram entries per query of a complete sample
+  uint32_t expect;          // sample slots per query (two per sample block; a multiple of 4, <= TS_FUSED_MAX_KEYS)
   uint32_t gen;             // generation tag of the launch (non-zero, unique per workspace set)
   uint32_t arrive_goal;     // value of *arrive once every sample wave has reported
   uint32_t wait_iters;      // bound of every in-kernel spin
-  uint32_t* hist;           // [64][16384] uint32, all-zero between launches
+  uint32_t* skeys;          // ts_fused_keys_bytes(): [64][TS_FUSED_MAX_KEYS] sample keys, all-zero between launches
   uint32_t* arrive;
   unsigned long long* tau64;   // [64]
   float* spill;             // ts_fused_spill_bytes()
@@ -181,7 +181,8 @@ struct TsFusedArgs {
   int32_t* cand_id;
   uint32_t cand_cap;
 };
-size_t ts_fused_hist_bytes();
+#define TS_FUSED_MAX_KEYS 24576   // the threshold role selects among them in LDS (96 KiB)
+size_t ts_fused_keys_bytes();
 size_t ts_fused_spill_bytes(int scan_wgs, int spill_rounds);
 int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t stream);
 

@@ -11,13 +11,12 @@
 //   * A wave's first `sample_rounds` row blocks double as the threshold SAMPLE: the blocks of round
 //     r are w + r*W for wave w, i.e. a contiguous prefix of W*32 rows per round … which is why the
 //     host side hands the waves a STRIDED block order for those rounds (see blk_of()).  For every
-//     (lane, query half) the maximum of the lane's 16 scores goes into a per-query histogram of the
-//     top 14 bits of the score's order-preserving key (agent-scope atomicAdd: performed memory-side,
-//     coherent across the 8 XCD L2s by construction).
+//     (lane, query half) the maximum of the lane's 16 scores — its order-preserving 32-bit key — is
+//     stored into the query's slot array with ONE agent-scope atomic store (a slot holds 0 or its
+//     final key; key 0 is never produced).
 //   * workgroups [scan_wgs, scan_wgs + tau_wgs) run on the CUs the scan grid leaves free.  They
-//     wait until a query's histogram holds every expected entry (the total is re-counted on every
-//     walk, so the test does not rely on any ordering between different addresses), take the lower
-//     edge of the bin that holds the m-th largest group maximum as the threshold, give the bins
+//     reload a query's slots until none is 0 (so readiness does not rely on any ordering between
+//     different addresses), select the m-th largest key EXACTLY (radix select in LDS), give the slots
 //     back as zeros and publish (generation, threshold) as ONE 64-bit atomic store per query.
 //   * A scan wave never waits in the common case: until its lanes see this launch's generation in
 //     the thresholds it keeps streaming and parks the dense 32x64 score tiles of its blocks in a
@@ -27,14 +26,14 @@
 //     wave that gives up poisons the candidate count so that the exactness verification of
 //     ts_index.hip redoes the batch on the dense path: every wave reaches its exit.
 //
-// Any threshold is a SAFE threshold (ts_index.hip verifies the candidate counts), so the histogram
-// resolution (2^-5 relative: ~20 % in candidate count) and the group maxima (the m-th largest of
-// per-16-row maxima is the m-th largest score as long as m is far below the number of groups; the
-// host only takes this path for N >= 256 k) only decide how many candidates survive.
+// Any threshold is a SAFE threshold (ts_index.hip verifies the candidate counts); the group maxima (the
+// m-th largest of per-16-row maxima is the m-th largest sample score as long as m is far below the
+// number of groups; the host only takes this path while 4 m <= groups) only decide how many
+// candidates survive.  (A first version estimated the threshold from a 14-bit histogram of the keys:
+// with real embedding models, whose scores sit in a narrow band, one bin held a third of the corpus.)
 #include "ts_scan_dev.h"
+#include <algorithm>
 
-#define TS_HIST_BITS 14
-#define TS_HIST_BINS (1 << TS_HIST_BITS)
 
 __device__ __forceinline__ uint32_t fz_key(float f) {
   if (f != f) return 0u;
@@ -65,15 +64,16 @@ struct FusedParams {
   int dim;
   int q_vec;                // query rows can be read 8 elements at a time
   int scan_wgs, tau_wgs;
-  int sample_rounds;        // R: rounds whose blocks feed the histogram
+  int64_t n_sample;         // row blocks that feed the threshold sample (each wave's first rounds)
   int spill_rounds;         // capacity of the spill area, in rounds
   int64_t sample_stride;    // block stride of the sample rounds (see blk_of)
   uint32_t m;               // wanted rank among the group maxima
-  uint32_t expect;          // histogram entries per query when the sample is complete
+  uint32_t expect;          // slots per query of a complete sample (<= TS_FUSED_MAX_KEYS)
+  uint32_t keys_ld;         // slots between consecutive queries
   uint32_t gen;             // generation tag of this launch (never 0)
   uint32_t arrive_goal;     // value of *arrive when every sample wave has reported (hint only)
   uint32_t wait_iters;      // bound of every spin loop
-  uint32_t* hist;           // [64][TS_HIST_BINS], all-zero between launches
+  uint32_t* skeys;          // [64][keys_ld] sample keys, all-zero between launches
   uint32_t* arrive;         // monotonic hint counter
   unsigned long long* tau64;  // [64] (generation << 32) | float bits
   float* spill;             // [spill_rounds][scan waves][64][32]
@@ -157,11 +157,13 @@ __device__ __forceinline__ bool tau_wait(const FusedParams& p, float (&tau)[QH],
 
 // ---- threshold workgroups ---------------------------------------------------------------------
 __device__ void tau_role(const FusedParams& p, int tw, unsigned char* smem) {
-  uint32_t* wsum = reinterpret_cast<uint32_t*>(smem);   // [SCAN_WAVES] + [0..3] results
-  uint32_t* res = wsum + 16;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);    // [256]
+  uint32_t* wtot = hist + 256;                           // [4]
+  uint32_t* res = wtot + 8;                              // [0] digit, [1] rank left, [2] flags
+  uint32_t* keys = res + 8;                              // [expect]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int PER = TS_HIST_BINS / SCAN_THREADS;       // bins per thread (32)
-  // the hint: all sample waves have reported (bounded; the walk below re-checks by counting)
+  const uint32_t n = p.expect;
+  // the hint: all sample waves have reported (bounded; the loads below re-check slot by slot)
   if (tid == 0) {
     for (uint32_t it = 0; it < p.wait_iters; ++it) {
       const uint32_t cur = __hip_atomic_load(p.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -177,67 +179,71 @@ __device__ void tau_role(const FusedParams& p, int tw, unsigned char* smem) {
                            __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
-    uint32_t* hq = p.hist + (size_t)q * TS_HIST_BINS + (size_t)tid * PER;
-    u32x4 v[PER / 4];
-    uint32_t mine = 0, above = 0, total = 0;
+    uint32_t* src = p.skeys + (size_t)q * p.keys_ld;
+    // ---- slots -> LDS, until every one of them holds a key
     bool complete = false;
     for (uint32_t it = 0; it < p.wait_iters && !complete; ++it) {
-      mine = 0;
-#pragma unroll
-      for (int i = 0; i < PER / 4; ++i) {
-        v[i] = coherent_load16(hq + 4 * i);
-        mine += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-      }
-      // entries in the bins ABOVE this thread's (higher thread index = larger scores)
-      uint32_t incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_down((int)incl, o, 64);
-        if (lane + o < 64) incl += t;
-      }
-      __syncthreads();   // (wsum / res of the previous round or query are no longer read)
-      if (lane == 0) wsum[wave] = incl;
       __syncthreads();
-      above = incl - mine;
-      total = 0;
-#pragma unroll
-      for (int w2 = 0; w2 < SCAN_WAVES; ++w2) {
-        const uint32_t x = wsum[w2];
-        if (w2 > wave) above += x;
-        total += x;
+      if (tid == 0) res[2] = 0u;
+      __syncthreads();
+      bool hole = false;
+      for (uint32_t i = 4 * tid; i < n; i += 4 * SCAN_THREADS) {   // (n is a multiple of 4: two slots per sample item, items even)
+        const u32x4 v = coherent_load16(src + i);
+        keys[i] = v[0]; keys[i + 1] = v[1]; keys[i + 2] = v[2]; keys[i + 3] = v[3];
+        hole |= (v[0] == 0u) | (v[1] == 0u) | (v[2] == 0u) | (v[3] == 0u);
       }
-      complete = total >= p.expect;
+      if (__builtin_amdgcn_ballot_w64(hole) != 0ull && lane == 0) res[2] = 1u;
+      __syncthreads();
+      complete = res[2] == 0u;
       if (!complete) __builtin_amdgcn_s_sleep(64);
     }
-    // the bin holding the m-th largest entry (or the lowest non-empty one if there are fewer)
-    const uint32_t want = p.m < total ? p.m : total;
-    if (tid == 0) res[0] = 0u;
-    __syncthreads();
-    if (complete && want > 0 && above < want && above + mine >= want) {
-      uint32_t acc = above;
-      int bin = 0;
-#pragma unroll
-      for (int i = PER - 1; i >= 0; --i) {
-        const uint32_t c = v[i >> 2][i & 3];
-        if (acc < want && acc + c >= want) bin = tid * PER + i;
-        acc += c;
-      }
-      res[0] = (uint32_t)bin + 1u;
-    }
-    // give the bins back as zeros (the sample is complete: nobody adds to them any more)
+    uint32_t tkey = 0u;
     if (complete) {
+      // ---- the m-th largest key: MSB-first radix select, 8 bits per pass, in LDS
+      uint32_t prefix = 0u, krem = p.m < n ? p.m : n;
+      int bits = 0;
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        __syncthreads();
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += SCAN_THREADS) {
+          const uint32_t key = keys[i];
+          if (bits == 0 || (key >> (32 - bits)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // bin holding the krem-th largest: suffix sums over the 256 bins (4 waves x 64 lanes)
+        uint32_t own = 0u, v = 0u;
+        if (tid < 256) {
+          own = hist[tid];
+          v = own;
 #pragma unroll
-      for (int i = 0; i < PER / 4; ++i)
-        if ((v[i][0] | v[i][1] | v[i][2] | v[i][3]) != 0u) coherent_store16(hq + 4 * i, u32x4{0u, 0u, 0u, 0u});
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_down((int)v, o, 64);
+            if (lane + o < 64) v += t;
+          }
+          if (lane == 0) wtot[wave] = v;
+        }
+        __syncthreads();
+        if (tid < 256) {
+          for (int w2 = wave + 1; w2 < 4; ++w2) v += wtot[w2];   // entries in bins >= tid
+          const uint32_t above = v - own;
+          if (v >= krem && above < krem) { res[0] = (uint32_t)tid; res[1] = krem - above; }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | res[0];
+        krem = res[1];
+        bits += 8;
+      }
+      tkey = prefix;
+      // give the slots back as zeros (the sample is complete: nobody writes them any more)
+      for (uint32_t i = 4 * tid; i < n; i += 4 * SCAN_THREADS) coherent_store16(src + i, u32x4{0u, 0u, 0u, 0u});
     }
-    __syncthreads();
     if (tid == 0) {
-      // lower edge of the bin: scores >= it pass.  No complete sample within the bound (e.g. the scan
+      // scores >= the m-th largest group maximum pass.  No complete sample within the bound (e.g. the scan
       // workgroups never became resident): nothing passes and the verification redoes the batch.
-      uint32_t bits = 0x7f7fffffu;   // +FLT_MAX
-      if (complete && res[0] != 0u) bits = __builtin_bit_cast(uint32_t, fz_unkey((res[0] - 1u) << (32 - TS_HIST_BITS)));
-      else if (complete) bits = 0xff7fffffu;   // empty sample (cannot happen for nwork > 0): everything passes
-      __hip_atomic_store(p.tau64 + q, ((unsigned long long)p.gen << 32) | (unsigned long long)bits, __ATOMIC_RELAXED,
+      const uint32_t bits32 = complete ? __builtin_bit_cast(uint32_t, fz_unkey(tkey)) : 0x7f7fffffu;
+      __hip_atomic_store(p.tau64 + q, ((unsigned long long)p.gen << 32) | (unsigned long long)bits32, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -296,12 +302,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   BlockOrder order;
   order.nblk = p.sp.nwork;
   order.stride = p.sample_stride;
-  {
-    const int64_t want = (int64_t)p.sample_rounds * nwaves;
-    order.n_sample = want < order.nblk ? want : order.nblk;
-    if (order.stride > 1 && order.n_sample * order.stride > order.nblk) order.n_sample = order.nblk / order.stride;
-    order.n_rest = order.nblk - order.n_sample;
-  }
+  order.n_sample = p.n_sample;   // (host: n_sample * stride <= nblk)
+  order.n_rest = order.nblk - order.n_sample;
   // work item j of this wave: sample item w + j*W while that is < n_sample, then the rest blocks
   const int64_t my_sample = w < order.n_sample ? (order.n_sample - w + nwaves - 1) / nwaves : 0;
   const int64_t my_rest = w < order.n_rest ? (order.n_rest - w + nwaves - 1) / nwaves : 0;
@@ -388,13 +390,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
 
       // ---- epilogue
       if (j < my_sample) {
-        // sample round: the lane's group maxima -> histogram
+        // sample round: the lane's group maximum -> its slot of the query's key array
+        const int64_t slot = 2 * (w + j * nwaves) + (lane >> 5);
 #pragma unroll
         for (int hq = 0; hq < QH; ++hq) {
           const int q = hq * 32 + (lane & 31);
           if (q < p.sp.nq) {
-            const uint32_t bin = fz_key(acc_max(acc[hq])) >> (32 - TS_HIST_BITS);
-            atomicAdd(p.hist + (size_t)q * TS_HIST_BINS + bin, 1u);
+            uint32_t key = fz_key(acc_max(acc[hq]));
+            key = key ? key : 1u;   // (0 means "not written yet"; only a NaN score maps there)
+            __hip_atomic_store(p.skeys + (size_t)q * p.keys_ld + slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         if (j + 1 == my_sample && lane == 0) atomicAdd(p.arrive, 1u);   // (a hint; see tau_role)
@@ -450,7 +454,7 @@ static int launch_fused_t(const FusedParams& p, int grid, size_t lds, hipStream_
   return TS_OK;
 }
 
-size_t ts_fused_hist_bytes() { return (size_t)TS_MAX_Q * TS_HIST_BINS * sizeof(uint32_t); }
+size_t ts_fused_keys_bytes() { return (size_t)TS_MAX_Q * TS_FUSED_MAX_KEYS * sizeof(uint32_t); }
 size_t ts_fused_spill_bytes(int scan_wgs, int spill_rounds) {
   return (size_t)spill_rounds * scan_wgs * SCAN_WAVES * TS_MAX_Q * 32 * sizeof(float);
 }
@@ -476,7 +480,7 @@ int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t
              (reinterpret_cast<uintptr_t>(a.queries) % (esz == 4 ? 32 : 16)) == 0) ? 1 : 0;
   p.scan_wgs = a.scan_wgs;
   p.tau_wgs = a.tau_wgs;
-  p.sample_rounds = a.sample_rounds;
+  p.n_sample = a.n_sample;
   p.spill_rounds = a.spill_rounds;
   p.sample_stride = a.sample_stride;
   p.m = a.m;
@@ -484,11 +488,18 @@ int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t
   p.gen = a.gen;
   p.arrive_goal = a.arrive_goal;
   p.wait_iters = a.wait_iters;
-  p.hist = a.hist;
+  p.skeys = a.skeys;
+  p.keys_ld = TS_FUSED_MAX_KEYS;
   p.arrive = a.arrive;
   p.tau64 = a.tau64;
   p.spill = a.spill;
-  const size_t lds = ts_scan_lds_bytes(L, qh);
+  // every workgroup gets the same dynamic LDS: the scan's query image + staging, or the threshold role's keys
+  const size_t lds = std::max(ts_scan_lds_bytes(L, qh), (size_t)a.expect * 4 + 4096);
+  if (a.expect > TS_FUSED_MAX_KEYS || (a.expect & 3u) || lds > 160 * 1024 || a.expect != 2 * a.n_sample ||
+      a.n_sample * a.sample_stride > a.nblk || a.n_sample < 1 || a.sample_stride < 1) {
+    ts_set_error("one-launch search: bad sample geometry (%u slots)", a.expect);
+    return TS_ERR_INVALID;
+  }
   const int grid = a.scan_wgs + a.tau_wgs;
   if (qh == 1) {
     switch (L.dtype) {

@@ -492,8 +492,8 @@ static int ensure_streams(ts_index* h) {
 // workspace sets; a set is reused only after the Sel that last read it (its ev_sel).
 // ---- geometry of the one-launch search
 struct FusedPlan {
-  int scan_wgs, tau_wgs, sample_rounds, spill_rounds;
-  int64_t sample_stride, sample_rows;
+  int scan_wgs, tau_wgs, spill_rounds;
+  int64_t n_sample, sample_stride, sample_rows;
   uint32_t m, expect, sample_waves;
 };
 static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool pipe, FusedPlan* fp) {
@@ -506,13 +506,14 @@ static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool p
   if (dbg_cus > 0) scan_wgs = dbg_cus;
 #endif
   if (scan_wgs < 1) return false;
-  const int tau_wgs = std::max(1, std::min(32, h->num_cus - scan_wgs));
+  const int tau_wgs = std::max(1, std::min(64, h->num_cus - scan_wgs));
   const int64_t nwaves = (int64_t)scan_wgs * 8;
   if (nblk < nwaves) return false;                         // fewer row blocks than waves: a latency-bound corpus
   const int64_t want_rows = std::max(kMinSampleRows, N / kSampleDiv);
   int64_t R = (want_rows + nwaves * TS_ROWS_PER_BLOCK - 1) / (nwaves * TS_ROWS_PER_BLOCK);
   R = std::max<int64_t>(1, std::min<int64_t>(R, 16));
-  const int64_t n_sample = std::min(nblk, R * nwaves);
+  int64_t n_sample = std::min(nblk, R * nwaves);
+  n_sample = std::min<int64_t>(n_sample, TS_FUSED_MAX_KEYS / 2) & ~(int64_t)1;   // two slots per block, slots a multiple of 4
   const int64_t stride = std::max<int64_t>(1, nblk / n_sample);
   const int64_t rows = n_sample * TS_ROWS_PER_BLOCK;
   const int64_t oversample = k > 1024 ? 3 : kOversample;
@@ -522,8 +523,8 @@ static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool p
   if ((uint64_t)m * 4 > expect) return false;              // group maxima would no longer stand in for scores
   fp->scan_wgs = scan_wgs;
   fp->tau_wgs = tau_wgs;
-  fp->sample_rounds = (int)R;
-  fp->spill_rounds = (int)R + 4;
+  fp->n_sample = n_sample;
+  fp->spill_rounds = (int)((n_sample + nwaves - 1) / nwaves) + 4;
   fp->sample_stride = stride;
   fp->sample_rows = rows;
   fp->m = m;
@@ -637,12 +638,12 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   if (fused) {
     // ---- ONE launch: query image, thresholds and scan+filter (see ts_fused.hip)
     if (!W.hist.p) {
-      TS_CHECK(ensure(W.hist, ts_fused_hist_bytes()));
+      TS_CHECK(ensure(W.hist, ts_fused_keys_bytes()));
       W.hist_dirty = true;
     }
     TS_CHECK(ensure(W.spill, ts_fused_spill_bytes(fp.scan_wgs, fp.spill_rounds)));
     if (W.hist_dirty) {
-      TS_HIP(hipMemsetAsync(W.hist.p, 0, ts_fused_hist_bytes(), sS));
+      TS_HIP(hipMemsetAsync(W.hist.p, 0, ts_fused_keys_bytes(), sS));
       TS_HIP(hipMemsetAsync(W.cand_cnt(), 0, 256, sS));
       W.hist_dirty = false;
     }
@@ -657,7 +658,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     a.ntotal = N;
     a.scan_wgs = fp.scan_wgs;
     a.tau_wgs = fp.tau_wgs;
-    a.sample_rounds = fp.sample_rounds;
+    a.n_sample = fp.n_sample;
     a.spill_rounds = fp.spill_rounds;
     a.sample_stride = fp.sample_stride;
     a.m = fp.m;
@@ -665,7 +666,7 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     a.gen = W.gen;
     a.arrive_goal = W.arrive_total;
     a.wait_iters = 40000;
-    a.hist = (uint32_t*)W.hist.p;
+    a.skeys = (uint32_t*)W.hist.p;
     a.arrive = W.arrive();
     a.tau64 = W.tau64();
     a.spill = (float*)W.spill.p;

@@ -227,14 +227,21 @@ __device__ __forceinline__ void m16_finish_doc(const Ms16Params& p, int d, int l
 // Candidates this wave has left (lane i holds record i): add their tile counts to the arrival
 // counters; whoever brings a counter to its target finishes that candidate.
 __device__ __forceinline__ void m16_flush_records(const Ms16Params& p, int nrec, int rdoc,
-                                                  uint32_t rtiles, uint32_t rneed, int lane) {
-  // Order "my atomicMax are performed" before "my counts are performed" WITHOUT a fence: a
-  // release fence at agent scope is buffer_wbl2 sc1 — a write-back of the whole L2 — and 2048
-  // waves executing it made the kernel 3.5x slower (186 vs 53 us).  All the data involved is
-  // only ever touched by agent-scope atomics, which are performed at the coherence point, and
-  // vmcnt(0) returns when the L2 has acknowledged this wave's atomics.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  asm volatile("" ::: "memory");
+                                                  uint32_t rtiles, uint32_t rneed, int lane, uint32_t sink) {
+  // "My maxima are performed" must precede "my counts are performed".  A release fence at agent
+  // scope would do it inside the HIP memory model, but it is buffer_wbl2 sc1 — a write-back of the
+  // whole L2 — and 2048 waves executing it made the kernel 3.5x slower (186 vs 53 us).  Instead every
+  // atomicMax of this wave is a RETURNING atomic and `sink` is a value computed from all the
+  // returned words: an atomic's return value comes from the place where the read-modify-write was
+  // performed (for agent scope: memory-side, the one copy all 8 XCDs see), so once `sink` exists
+  // every maximum of this wave has been performed, and the atomicAdd below — which consumes
+  // `sink` — cannot issue earlier.  The finishing wave's own returning atomicAdd closes the chain:
+  // the count it sees includes only adds issued after their waves' maxima were performed, and it
+  // reads the maxima with agent-scope atomic loads issued after that add returned.  (Every word
+  // involved is only ever touched by agent-scope atomics: no cached copy can go stale.)
+  // (`sink` is an input of this empty statement: the compiler has to wait for the returns that feed it
+  // before this point, and the atomicAdd below — whose operand passes through it — is issued after it)
+  asm volatile("" : "+v"(rtiles) : "v"(sink) : "memory");
   uint32_t old = 0;
   if (lane < nrec) old = atomicAdd(p.cnt + rdoc, rtiles);
   const bool last = lane < nrec && old + rtiles == rneed;  // (consuming `old` waits for the atomic)
@@ -312,6 +319,67 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       p.out[d] = 0.f;  // reference: a candidate that cannot be scored keeps 0.0 (:285-291)
   }
 
+  // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + the waves' totals).  This
+  // comes FIRST: the wave's first tile is known ~2 us after the kernel starts, its ring loads go
+  // out, and the query image below is staged while they cross the HBM latency (it used to be
+  // staged first: first loads in flight at 7 us, tools/trace_maxsim.py).
+  int incl = mytiles;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, T = 0;
+#pragma unroll
+  for (int w = 0; w < M16_WAVES; ++w) {
+    const int x = wsum[w];
+    base += (w < wave) ? x : 0;
+    T += x;
+  }
+  {
+    int run = base + incl - mytiles;
+    for (int d = d0; d < d1; ++d) {
+      prefix[d] = run;
+      const int len = m16_len(p, d);  // (L1/L2 hit: read a moment ago)
+      run += m16_tiles(len);
+    }
+    if (tid == 0) prefix[p.n_docs] = T;
+  }
+  __syncthreads();
+  M16_STAMP(1);
+
+  // ---- this wave's slice of the tile sequence (wave-major numbering spreads the longer
+  // slices over all workgroups)
+  const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
+  const int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
+  const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
+  const bool has_work = lo < hi;   // (a wave without tiles still stages its share of the query image)
+
+  int doc = 0, tile = 0, len = 1;
+  int64_t start = 0;
+  if (has_work) {
+    int a = 0, b = p.n_docs;  // prefix[a] <= lo < prefix[b]
+    while (b - a > 1) {
+      const int m = (a + b) >> 1;
+      if ((int64_t)prefix[m] <= lo) a = m; else b = m;
+    }
+    doc = __builtin_amdgcn_readfirstlane(a);
+    tile = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
+    len = m16_len_s(p, doc);
+    start = m16_start_s(p, doc);
+  }
+  const unsigned char* cur = p.docs;
+  u32x4 ring[M16_RING];
+  if (has_work) {
+    const int rows = min(32, len - tile * 32);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
+#pragma unroll
+    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
+  }
+  M16_STAMP(2);
+
   // ---- Q image: unit (g*NQT + t)*64 + l = the 16 bytes at byte 32g + 16(l>>5) of query row q0 + 32t + (l&31)
   // (8 independent L2 reads in flight per thread: one at a time costs ~1 us each)
   {
@@ -338,66 +406,11 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   // Explicit vmcnt(0): the stores above sit under a lane predicate, so on their skip path the
   // compiler's scoreboard still counts the staging loads as pending and would put a
   // vmcnt(0) in front of the first reuse of their registers — inside the tile loop, where it
-  // drains the ring once per tile.
+  // drains the ring once per tile.  (The ring's first loads are older than the staging loads and
+  // are needed next anyway.)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-  M16_STAMP(1);
-
-  // ---- exclusive prefix sums of tiles per candidate -> LDS (wave scan + the waves' totals)
-  int incl = mytiles;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  int base = 0, T = 0;
-#pragma unroll
-  for (int w = 0; w < M16_WAVES; ++w) {
-    const int x = wsum[w];
-    base += (w < wave) ? x : 0;
-    T += x;
-  }
-  {
-    int run = base + incl - mytiles;
-    for (int d = d0; d < d1; ++d) {
-      prefix[d] = run;
-      const int len = m16_len(p, d);  // (L1/L2 hit: read a moment ago)
-      run += m16_tiles(len);
-    }
-    if (tid == 0) prefix[p.n_docs] = T;
-  }
-  __syncthreads();
-
-  // ---- this wave's slice of the tile sequence (wave-major numbering spreads the longer
-  // slices over all workgroups)
-  const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
-  const int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
-  const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
-  M16_STAMP(2);
-  if (lo >= hi) return;  // (no block-level barrier below)
-
-  int doc, tile, len;
-  int64_t start;
-  {
-    int a = 0, b = p.n_docs;  // prefix[a] <= lo < prefix[b]
-    while (b - a > 1) {
-      const int m = (a + b) >> 1;
-      if ((int64_t)prefix[m] <= lo) a = m; else b = m;
-    }
-    doc = __builtin_amdgcn_readfirstlane(a);
-    tile = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
-    len = m16_len_s(p, doc);
-    start = m16_start_s(p, doc);
-  }
-  const unsigned char* cur;
-  u32x4 ring[M16_RING];
-  {
-    const int rows = min(32, len - tile * 32);
-    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
-#pragma unroll
-    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
-  }
+  if (!has_work) return;  // (no block-level barrier below)
 
   M16_STAMP(3);
   const u32x4* ql = qlds + lane;
@@ -425,6 +438,8 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   // candidates left behind: lane i keeps record i
   int nrec = 0, rdoc = 0;
   uint32_t rtiles = 0, rneed = 0, run_tiles = 0;
+  uint32_t sink = 0;        // folds the words returned by this wave's atomicMax (see m16_flush_records)
+  bool from_start = (tile == 0);   // this wave has seen the current candidate from its first tile on
 
   for (int64_t it = lo; it < hi; ++it) {
     // ---- next item of the slice (wave-uniform)
@@ -496,30 +511,68 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     ++run_tiles;
     if (it == lo) M16_STAMP(5);
 
-    // ---- leaving this candidate (or the slice): publish the maxima, remember the candidate
+    // ---- leaving this candidate (or the slice)
     if (!has_next || ndoc != doc) {
+      const bool to_end = tile + 1 >= m16_tiles(len);   // its last tile was this wave's
+      if (from_start && to_end && p.passes == 1) {
+        // The whole candidate went through THIS wave: its maxima are complete in registers — score it
+        // here, no scratch, no atomics.  Same values and the same summation tree as m16_finish_doc (lane L
+        // holds query token L: token 32t + r sits in lane (r, h = t)), hence bit-identical scores.
+        float v = 0.f;
 #pragma unroll
-      for (int t = 0; t < NQT; ++t) {
-        const float m = fmaxf(best[t], __shfl_xor(best[t], 32, 64)) * invq[t];
-        const int qi = q0 + 32 * t + r;
-        if (h == 0 && qi < p.Lq) atomicMax(p.best + (size_t)doc * p.lq_pad + qi, m16_key(m));
-        best[t] = M16_NEG;
-      }
-      if (lane == nrec) {
-        rdoc = doc;
-        rtiles = run_tiles;
-        rneed = (uint32_t)p.passes * (uint32_t)m16_tiles(len);
+        for (int t = 0; t < NQT; ++t) {
+          const float m = fmaxf(best[t], __shfl_xor(best[t], 32, 64)) * invq[t];
+          if (h == t && 32 * t + r < p.Lq) v = m;
+          best[t] = M16_NEG;
+        }
+        float res;
+        const bool has = (32 * h + r < p.Lq) && (h < NQT);
+        if (p.mode == 0) {
+          float sacc = has ? v : 0.f;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+          res = sacc / (float)p.Lq;
+        } else {
+          float mx = has ? v : M16_NEG;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+          const float e = has ? expf(v - mx) : 0.f;
+          float den = e, num = has ? e * v : 0.f;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            num += __shfl_xor(num, o, 64);
+            den += __shfl_xor(den, o, 64);
+          }
+          res = num / den;
+        }
+        if (lane == 0) p.out[doc] = res;
+      } else {
+        // shared with other waves (or other passes): publish the maxima, remember the candidate
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+          const float m = fmaxf(best[t], __shfl_xor(best[t], 32, 64)) * invq[t];
+          const int qi = q0 + 32 * t + r;
+          if (h == 0 && qi < p.Lq)
+            sink |= atomicMax(p.best + (size_t)doc * p.lq_pad + qi, m16_key(m));   // RETURNING: see m16_flush_records
+          best[t] = M16_NEG;
+        }
+        if (lane == nrec) {
+          rdoc = doc;
+          rtiles = run_tiles;
+          rneed = (uint32_t)p.passes * (uint32_t)m16_tiles(len);
+        }
+        if (++nrec == 64) {  // (only with very many tiny candidates per wave)
+          m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane, sink);
+          nrec = 0;
+        }
       }
       run_tiles = 0;
-      if (++nrec == 64) {  // (only with very many tiny candidates per wave)
-        m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane);
-        nrec = 0;
-      }
+      from_start = true;   // the next candidate (if any) starts at its tile 0
     }
     doc = ndoc; tile = ntile; len = nlen; start = nstart; cur = nxt;
   }
   M16_STAMP(6);
-  if (nrec) m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane);
+  if (nrec) m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane, sink);
   M16_STAMP(7);
 }
 

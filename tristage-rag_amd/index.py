@@ -74,6 +74,7 @@ class FlatIPIndex:
         self._pending_passes = 0
         self._auto_redone = []  # tickets repeated by an internal finish() the caller has not seen yet
         self.auto_finish = True  # False: the owner (ShardedFlatIPIndex) calls finish() itself, collectively
+        self.classic_filter = False  # True: every search takes the five-launch filter path (A/B measurements)
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -147,7 +148,7 @@ class FlatIPIndex:
         if k <= 0:
             raise ValueError("k must be positive")
         flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
-        if classic:   # the five-launch filter path even where the one-launch scan applies (A/B, tests)
+        if classic or self.classic_filter:   # the five-launch filter path even where the one-launch scan applies (A/B, tests)
             flags |= _lib.TS_FLAG_CLASSIC
         if async_:
             if not (_is_tensor(q) and q.is_cuda):
