@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of the timed region (stderr)")
     ap.add_argument("--ids", action="store_true",
                     help="stage-3 token ids cached at add time: search_many runs every stage on arrays (needs --store --many)")
+    ap.add_argument("--s3-batch", type=int, default=1024, help="pairs per cross-encoder forward in search_many")
+    ap.add_argument("--no-lean", action="store_true", help="stage 3 through the transformers module instead of the written-out forward")
     ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
@@ -51,8 +53,12 @@ def main():
                         stage1_index_dtype="f16", stage1_batch_size=64, stage2_batch_size=64,
                         stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
                         stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs,
-                        stage3_cache_document_tokens=args.ids, save_intermediate_results=args.keep)
+                        stage3_cache_document_tokens=args.ids, save_intermediate_results=args.keep,
+                        stage3_many_batch_size=args.s3_batch)
     p = RetrievalPipeline(config=pc)
+    p.initialize_stages()
+    if args.no_lean and hasattr(p.stage3.model, "lean_forward"):
+        p.stage3.model.lean_forward = False
     t0 = time.perf_counter()
     p.add_documents(docs)
     torch.cuda.synchronize()
@@ -97,7 +103,8 @@ def main():
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
                    "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
                    "queries_per_search_many": args.many, "bm25_rrf": args.bm25,
-                   "stage3_token_id_cache": args.ids, "save_intermediate_results": args.keep,
+                   "stage3_token_id_cache": args.ids, "stage3_pairs_per_forward": args.s3_batch,
+                   "stage3_lean_forward": bool(getattr(p.stage3.model, "_lean", None)), "save_intermediate_results": args.keep,
                    "array_path": bool(args.ids and args.store and args.many and getattr(p.stage3, "_pairs_usable", False))},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},

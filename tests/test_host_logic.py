@@ -609,3 +609,33 @@ def test_search_many_on_arrays_equals_the_record_path(encoder, tmp_path, bm25, f
             a.search_many(["zzz"], top_k=3)
         with pytest.raises(ZeroDivisionError):
             b.search_many(["zzz"], top_k=3)
+
+
+@pytest.mark.parametrize("spec", ["random:tiny", "random:minilm", "random:xlmr-large:64:2:4"])
+def test_lean_classifier_forward_equals_the_transformers_module(spec):
+    """encoders.LeanBertClassifier (fused QKV, no autocast cache, no mask for unpadded batches) is the same
+    arithmetic as the transformers module: identical logits in fp32, and in bf16 identical to the module under
+    torch.autocast (BERT and the RoBERTa family with its padding-aware position ids)."""
+    from tristage_rag_amd.encoders import LeanBertClassifier
+    m = CrossEncoderModel(spec, device="cpu", use_amp=False)
+    g = torch.Generator().manual_seed(0)
+    B, L = 9, 31
+    ids = torch.randint(1000, 20000, (B, L), generator=g)
+    lens = torch.randint(4, L + 1, (B,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    types = ((torch.arange(L)[None, :] >= 5) & mask.bool()).long()
+    for full in (False, True):                          # with padding / a batch without any (no mask tensor at all)
+        mm = torch.ones_like(mask) if full else mask
+        with torch.no_grad():
+            ref = m.model(input_ids=ids, attention_mask=mm, token_type_ids=types).logits.float()
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                ref16 = m.model(input_ids=ids, attention_mask=mm, token_type_ids=types).logits.float()
+        assert torch.allclose(LeanBertClassifier(m.model, None)(ids, mm, types), ref, atol=1e-6)
+        assert torch.allclose(LeanBertClassifier(m.model, torch.bfloat16)(ids, mm, types), ref16, atol=2e-3)
+    # CrossEncoderModel routes assembled id tensors through it; the switch restores the module's forward
+    enc = {"input_ids": ids, "attention_mask": mask, "token_type_ids": types}
+    a = m.logits_from_ids(enc)
+    m.lean_forward = False
+    assert torch.allclose(a, m.logits_from_ids(enc), atol=1e-6)

@@ -177,3 +177,57 @@ def test_hip_graph_query_forwards_match_eager(tmp_path):
         p.add_documents(docs)
         outs.append([[r["doc_id"] for r in p.search(q)["results"]] for q in ("neural network", "gpu memory index")])
     assert outs[0] == outs[1]
+
+
+def test_array_path_search_many_on_gpu(tmp_path):
+    """search_many with every stage on arrays (HIP index -> token-store MaxSim + device sort -> cross-encoder inputs
+    assembled on the GPU from cached token ids -> LeanBertClassifier) against the per-record path of the same
+    pipeline and against search(): same records; with BM25 + RRF too; fp32 so that the comparison is tight, then
+    bf16 (lean forward vs the transformers module under autocast) at bf16 tolerance."""
+    import torch
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    docs = _corpus(600)
+    queries = ["neural networks attention", "language retrieval system", "gpu memory index", docs[11], "vector search rank"]
+    for bm25 in (False, True):
+        pc = PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                            device="cuda", cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / "i"),
+                            log_file=str(tmp_path / f"a{bm25}.log"), log_level="WARNING", stage1_top_k=200, stage2_top_k=40,
+                            stage3_top_k=10, stage1_enable_bm25=bm25, stage1_use_fp16=False, stage2_use_fp16=False,
+                            stage3_use_fp16=False, save_intermediate_results=True,
+                            stage2_precompute_document_embeddings=True, stage3_cache_document_tokens=True)
+        p = RetrievalPipeline(config=pc)
+        p.add_documents(docs[:350])
+        p.add_documents(docs[350:])
+        assert p.stage3._pairs_usable and len(p.stage3._pairs) == len(docs)
+        fast = p.search_many(queries)
+        assert p._search_many_arrays(queries, 10) is not None
+        p.stage3._pairs_usable = False                       # the same pipeline, per-record path
+        slow = p.search_many(queries)
+        p.stage3._pairs_usable = True
+        for a, b, q in zip(fast, slow, queries):
+            one = p.search(q)
+            for other in (b, one):
+                for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                    ia, ib = [x["doc_id"] for x in a[stage]], [x["doc_id"] for x in other[stage]]
+                    sa, sb = np.array([x[key] for x in a[stage]]), np.array([x[key] for x in other[stage]])
+                    assert len(ia) == len(ib)
+                    np.testing.assert_allclose(sa, sb, atol=1e-4)
+                    for x, y, u, v in zip(ia, ib, sa, sb):
+                        assert x == y or abs(u - v) < 1e-4
+            assert set(a["results"][0]) == set(one["results"][0])
+    # bf16: the written-out forward vs the transformers module under autocast, on real assembled batches
+    from tristage_rag_amd.encoders import CrossEncoderModel, PairAssembler
+    ce = CrossEncoderModel("random:minilm", device="cuda", use_amp=True)
+    pa = PairAssembler(ce.tokenizer, 256)
+    pa.add_documents(docs)
+    pq = torch.arange(3, device="cuda").repeat_interleave(100)
+    pd = torch.randint(0, len(docs), (300,), device="cuda")
+    plan = pa.plan([pa.ids_of(q) for q in queries[:3]], pq, pd, "cuda")
+    enc = pa.batch(plan, torch.arange(300, device="cuda"))
+    lean = ce.logits_from_ids(enc)
+    assert ce._lean
+    ce.lean_forward = False
+    ref = ce.logits_from_ids(enc)
+    assert float((lean - ref).abs().max()) < 4e-3            # bf16 GEMMs of different shapes (fused QKV)
+    text = ce.logits([[queries[int(a)], docs[int(b)]] for a, b in zip(pq.tolist(), pd.tolist())], batch_size=300)
+    assert float((text - ref).abs().max()) < 4e-3            # assembled ids == tokenised text pairs

@@ -285,6 +285,31 @@ __device__ __forceinline__ u32x4 q_unit(const TIN* q, int nq, int dim, int dt, i
   return out;
 }
 
+// 8 independent units per thread and trip: their loads are in flight together (one unit at a time
+// is a chain of ~100 dependent L2 round trips per thread: it cost ~100 us per launch)
+template <typename TIN, int DT, int QH>
+__device__ __forceinline__ void build_qimage(const FusedParams& p, u32x4* qlds, int tid) {
+  const int units = p.sp.kg * QH * 64;
+  const TIN* q = reinterpret_cast<const TIN*>(p.queries);
+  for (int t0 = tid; t0 < units; t0 += 8 * SCAN_THREADS) {
+    u32x4 u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + i * SCAN_THREADS;
+      const int tt = t < units ? t : t0;          // (always a valid unit: no branch around the loads)
+      const int l = tt & 63;
+      const int hq = (tt >> 6) % QH;
+      const int g = (tt >> 6) / QH;
+      u[i] = q_unit<TIN>(q, p.sp.nq, p.dim, DT, g, l >> 5, hq * 32 + (l & 31), p.q_vec);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + i * SCAN_THREADS;
+      if (t < units) qlds[t] = u[i];
+    }
+  }
+}
+
 template <int DT, int QH>
 __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -325,20 +350,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   }
 
   // ---- prologue: the query image is built in LDS from the caller's rows
-  {
-    const int units = kg * QH * 64;
-    for (int t = tid; t < units; t += SCAN_THREADS) {
-      const int l = t & 63;
-      const int hq = (t >> 6) % QH;
-      const int g = (t >> 6) / QH;
-      const int qi = hq * 32 + (l & 31), h = l >> 5;
-      u32x4 u;
-      if (p.q_dtype == TS_F32) u = q_unit<float>((const float*)p.queries, p.sp.nq, p.dim, DT, g, h, qi, p.q_vec);
-      else if (p.q_dtype == TS_F16) u = q_unit<_Float16>((const _Float16*)p.queries, p.sp.nq, p.dim, DT, g, h, qi, p.q_vec);
-      else u = q_unit<__bf16>((const __bf16*)p.queries, p.sp.nq, p.dim, DT, g, h, qi, p.q_vec);
-      qlds[t] = u;
-    }
-  }
+  if (p.q_dtype == TS_F32) build_qimage<float, DT, QH>(p, qlds, tid);
+  else if (p.q_dtype == TS_F16) build_qimage<_Float16, DT, QH>(p, qlds, tid);
+  else build_qimage<__bf16, DT, QH>(p, qlds, tid);
   StageLds* st = reinterpret_cast<StageLds*>(smem + (size_t)kg * QH * 1024);
   if (tid == 0) st->cnt = 0;
   // (the staging loop's loads sit under lane predicates: make the compiler's scoreboard forget them
