@@ -61,6 +61,9 @@ def parse_args():
                          "(the NULL stream synchronises implicitly with every blocking stream of the process: "
                          "0.332 -> 0.324 ms per batch at 1.25 M rows per rank), the NULL stream otherwise")
     ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--one-launch", action="store_true",
+                    help="A/B: the one-launch scan (query image + thresholds + scan+filter in one kernel) also where the "
+                         "five-launch path is the default (pipelined submission, corpora above 4 M rows)")
     ap.add_argument("--classic", action="store_true",
                     help="A/B: the five-launch filter path (query prep, sample scan, thresholds, scan+filter, select) "
                          "instead of the one-launch scan")
@@ -208,6 +211,7 @@ def main():
     lo, hi = shard_bounds(args.rows, world, rank)
     local = FlatIPIndex(args.dim, dtype=args.dtype, device=local_rank)
     local.classic_filter = args.classic or bool(os.environ.get("TS_BENCH_CLASSIC"))
+    local.one_launch_filter = args.one_launch
     local.reserve(max(hi - lo, 1))
     blk = 500_000
     for r0 in range(lo, hi, blk):

@@ -70,8 +70,11 @@ enum ts_metric { TS_METRIC_INNER_PRODUCT = 0 };
                                    the call on `stream` as usual.                             */
 #define TS_FLAG_CLASSIC 32u     /* search: take the five-launch filter path (query prep, sample scan,
                                    thresholds, scan+filter, select) even where the one-launch scan
-                                   (query image, thresholds and scan+filter in ONE kernel) applies:
-                                   A/B measurements and tests; results are identical            */
+                                   (query image, thresholds and scan+filter in ONE kernel) is the
+                                   default: A/B measurements and tests; results are identical    */
+#define TS_FLAG_ONE_LAUNCH 64u  /* search: take the one-launch scan wherever its threshold estimate is
+                                   valid, also where the five-launch path is the default (pipelined
+                                   submission, corpora above 4 M rows); results are identical      */
 #define TS_FLAG_NORMALIZE 4u    /* add: L2-normalise rows x/(|x|+1e-8) on device first
                                    (reference src/stage1_retriever.py:285-288) */
 

@@ -520,9 +520,10 @@ def test_one_launch_scan_equals_five_launch_path_and_oracle(torch_mod, dtype, n,
     assert idx.last_search_info()["path"] == "filter" and not idx.last_search_info()["one_launch"]
     assert torch.equal(I, Ic) and torch.equal(D, Dc)
     check_topk(D.cpu().numpy()[:6], I.cpu().numpy()[:6], corpus, queries[:6], k)
-    for ready in (False, True):
-        outs = [idx.search(q, k, async_=True, inputs_ready=ready) for _ in range(7)]
+    for ready, force in ((False, False), (True, False), (True, True)):   # async; pipelined (five launches by default); pipelined one-launch
+        outs = [idx.search(q, k, async_=True, inputs_ready=ready, one_launch=force) for _ in range(7)]
         assert idx.finish() == []
+        assert idx.last_search_info()["one_launch"] == (force or not ready)
         for Da, Ia in outs:
             assert torch.equal(Ia, I) and torch.equal(Da, D)
     Dh, Ih = idx.search(queries, k)                              # host pointers

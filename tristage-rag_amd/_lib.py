@@ -19,7 +19,7 @@ TS_OK = 0
 TS_ERR_INVALID, TS_ERR_HIP, TS_ERR_OOM, TS_ERR_EMPTY, TS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 TS_F32, TS_F16, TS_BF16 = 0, 1, 2
 TS_METRIC_INNER_PRODUCT = 0
-TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE, TS_FLAG_ASYNC, TS_FLAG_PIPELINE, TS_FLAG_CLASSIC = 1, 2, 4, 8, 16, 32
+TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE, TS_FLAG_ASYNC, TS_FLAG_PIPELINE, TS_FLAG_CLASSIC, TS_FLAG_ONE_LAUNCH = 1, 2, 4, 8, 16, 32, 64
 
 # name -> (restype, argtypes); mirrors include/tristage.h one to one
 SIGNATURES = {

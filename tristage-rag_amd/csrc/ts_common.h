@@ -165,7 +165,6 @@ struct TsFusedArgs {
   int64_t nblk, ntotal;
   int scan_wgs, tau_wgs;    // workgroups streaming the corpus / estimating the thresholds
   int64_t n_sample;         // row blocks that feed the threshold sample: sample item s is block s*sample_stride
-  int spill_rounds;         // rounds a wave may park before it has to wait for the thresholds
   int64_t sample_stride;    // sample item s is row block s*sample_stride
   uint32_t m;               // wanted rank among the sample's 16-row group maxima
   uint32_t expect;          // sample slots per query (two per sample block; a multiple of 4, <= TS_FUSED_MAX_KEYS)
@@ -175,15 +174,13 @@ struct TsFusedArgs {
   uint32_t* skeys;          // ts_fused_keys_bytes(): [64][TS_FUSED_MAX_KEYS] sample keys, all-zero between launches
   uint32_t* arrive;
   unsigned long long* tau64;   // [64]
-  float* spill;             // ts_fused_spill_bytes()
   uint32_t* cand_cnt;       // [64], zero at launch
   float* cand_score;
   int32_t* cand_id;
   uint32_t cand_cap;
 };
-#define TS_FUSED_MAX_KEYS 24576   // the threshold role selects among them in LDS (96 KiB)
+#define TS_FUSED_MAX_KEYS 12288   // per query; the threshold role selects among two queries' keys in LDS (96 KiB)
 size_t ts_fused_keys_bytes();
-size_t ts_fused_spill_bytes(int scan_wgs, int spill_rounds);
 int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- select

@@ -18,13 +18,14 @@
 //     reload a query's slots until none is 0 (so readiness does not rely on any ordering between
 //     different addresses), select the m-th largest key EXACTLY (radix select in LDS), give the slots
 //     back as zeros and publish (generation, threshold) as ONE 64-bit atomic store per query.
-//   * A scan wave never waits in the common case: until its lanes see this launch's generation in
-//     the thresholds it keeps streaming and parks the dense 32x64 score tiles of its blocks in a
-//     private spill area (8 KiB per block, re-read by the same wave only), then switches to the
-//     fused filter epilogue and re-filters the parked tiles after its last block.  Only if the
-//     spill area is exhausted, or at the very end, does it spin — every spin is bounded, and a
-//     wave that gives up poisons the candidate count so that the exactness verification of
-//     ts_index.hip redoes the batch on the dense path: every wave reaches its exit.
+//   * Until a scan wave sees this launch's thresholds it keeps streaming and PARKS the 32x64 score tiles
+//     of its blocks in registers (two tiles, 64 VGPRs); when the thresholds arrive it filters the parked
+//     tiles and goes on with the fused filter epilogue.  A third tile before the thresholds, or the end
+//     of its blocks, makes it spin — every spin is bounded, and a wave that gives up poisons the
+//     candidate count so that the exactness verification of ts_index.hip redoes the batch on the dense
+//     path: every wave reaches its exit.  (Parking in global memory was tried first: on gfx9 stores share
+//     vmcnt with the corpus ring, every parked block drained the ring, 20-30 us per block instead of
+//     13, tools/trace_fused.py.)
 //
 // Any threshold is a SAFE threshold (ts_index.hip verifies the candidate counts); the group maxima (the
 // m-th largest of per-16-row maxima is the m-th largest sample score as long as m is far below the
@@ -64,8 +65,8 @@ struct FusedParams {
   int dim;
   int q_vec;                // query rows can be read 8 elements at a time
   int scan_wgs, tau_wgs;
+  int tau_waves;            // waves of a threshold workgroup that take queries (their key arrays share its LDS)
   int64_t n_sample;         // row blocks that feed the threshold sample (each wave's first rounds)
-  int spill_rounds;         // capacity of the spill area, in rounds
   int64_t sample_stride;    // block stride of the sample rounds (see blk_of)
   uint32_t m;               // wanted rank among the group maxima
   uint32_t expect;          // slots per query of a complete sample (<= TS_FUSED_MAX_KEYS)
@@ -76,7 +77,6 @@ struct FusedParams {
   uint32_t* skeys;          // [64][keys_ld] sample keys, all-zero between launches
   uint32_t* arrive;         // monotonic hint counter
   unsigned long long* tau64;  // [64] (generation << 32) | float bits
-  float* spill;             // [spill_rounds][scan waves][64][32]
 };
 
 // ---- block order ------------------------------------------------------------------------------
@@ -86,167 +86,209 @@ struct FusedParams {
 // s*stride, and the interleaved rounds skip those blocks.  To keep the index arithmetic trivial the
 // host chooses stride so that the sample blocks are exactly the multiples of `stride` below
 // n_sample*stride, and the remaining blocks are enumerated by skipping them.
+//
+// The sample blocks come in GROUPS of SAMPLE_GROUP consecutive blocks (the 8 waves of a workgroup read one
+// contiguous 8-block run): 1792 waves each opening its own 2 MiB page somewhere in the corpus was a TLB-miss
+// storm at kernel start (first block done after 30-56 us instead of ~14, tools/trace_fused.py); groups keep
+// the sample spread over n_sample/8 positions with an eighth of the page walks.
+#define SAMPLE_GROUP 8
 struct BlockOrder {
-  int64_t nblk, n_sample, stride, n_rest;
+  int64_t nblk, n_sample, stride, n_rest;   // stride: distance between the first blocks of consecutive groups
 };
+__device__ __forceinline__ int64_t sample_block(const BlockOrder& o, int64_t s) {
+  return (s / SAMPLE_GROUP) * o.stride + (s % SAMPLE_GROUP);
+}
 __device__ __forceinline__ int64_t rest_block(const BlockOrder& o, int64_t t) {
-  // t-th block (in ascending order) that is not a sample block.  Below n_sample*stride every run of
-  // `stride` blocks holds stride-1 of them.
-  if (o.stride <= 1) return o.n_sample + t;
-  const int64_t per = o.stride - 1;
-  const int64_t full = o.n_sample * per;
-  if (t >= full) return o.n_sample * o.stride + (t - full);
-  return (t / per) * o.stride + 1 + (t % per);
+  // t-th block (in ascending order) that is not a sample block.  Below n_groups*stride every run of
+  // `stride` blocks starts with SAMPLE_GROUP sample blocks.
+  const int64_t n_groups = o.n_sample / SAMPLE_GROUP;
+  const int64_t per = o.stride - SAMPLE_GROUP;
+  if (per <= 0) return o.n_sample + t;
+  const int64_t full = n_groups * per;
+  if (t >= full) return n_groups * o.stride + (t - full);
+  return (t / per) * o.stride + SAMPLE_GROUP + (t % per);
 }
 
+// The thresholds reach a scan workgroup through ONE wave: wave 0 polls the 64 published (generation,
+// threshold) words with agent-scope loads and hands them to its seven siblings through LDS.  (Every
+// wave polling by itself — 1792 waves x 64 lanes hitting the same 512 bytes with L2-bypassing loads
+// once per block — made each block of the parking phase 3x slower than a streaming block: the loads
+// queue up at one memory channel and the ring's loads return in order behind them, tools/trace_fused.py.)
 template <int QH>
-__device__ __forceinline__ void spill_store(float* dst, const f32x16 (&acc)[QH], int lane) {
-  const int j = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void tau_fetch(const FusedParams& p, unsigned long long (&tq)[2], int lane) {
 #pragma unroll
-  for (int hq = 0; hq < QH; ++hq) {
-    float* q = dst + (hq * 32 + j) * 32 + 4 * h;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      float4 v;
-      v.x = acc[hq][4 * r4 + 0]; v.y = acc[hq][4 * r4 + 1]; v.z = acc[hq][4 * r4 + 2]; v.w = acc[hq][4 * r4 + 3];
-      *reinterpret_cast<float4*>(q + 8 * r4) = v;
-    }
-  }
-}
-template <int QH>
-__device__ __forceinline__ void spill_load(const float* src, f32x16 (&acc)[QH], int lane) {
-  const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int hq = 0; hq < QH; ++hq) {
-    const float* q = src + (hq * 32 + j) * 32 + 4 * h;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const float4 v = *reinterpret_cast<const float4*>(q + 8 * r4);
-      acc[hq][4 * r4 + 0] = v.x; acc[hq][4 * r4 + 1] = v.y; acc[hq][4 * r4 + 2] = v.z; acc[hq][4 * r4 + 3] = v.w;
-    }
-  }
-}
-
-// this lane's thresholds, once every lane of the wave sees the launch's generation
-template <int QH>
-__device__ __forceinline__ bool tau_ready(const FusedParams& p, const unsigned long long (&tq)[QH], float (&tau)[QH]) {
-  bool ok = true;
-#pragma unroll
-  for (int hq = 0; hq < QH; ++hq) ok &= ((uint32_t)(tq[hq] >> 32) == p.gen);
-  if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return false;
-#pragma unroll
-  for (int hq = 0; hq < QH; ++hq) tau[hq] = __builtin_bit_cast(float, (uint32_t)tq[hq]);
-  return true;
-}
-template <int QH>
-__device__ __forceinline__ void tau_fetch(const FusedParams& p, unsigned long long (&tq)[QH], int lane) {
-#pragma unroll
-  for (int hq = 0; hq < QH; ++hq)
+  for (int hq = 0; hq < 2; ++hq)   // (all 64 thresholds, whatever QH is: the siblings' lanes need theirs)
     tq[hq] = __hip_atomic_load(p.tau64 + hq * 32 + (lane & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// wave 0 only: true (and the thresholds are in LDS, flag set) once every lane sees the launch's generation
+__device__ __forceinline__ bool tau_publish_lds(const FusedParams& p, StageLds* st, const unsigned long long (&tq)[2], int lane) {
+  const bool ok = ((uint32_t)(tq[0] >> 32) == p.gen) && ((uint32_t)(tq[1] >> 32) == p.gen);
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return false;
+  // values first, flag second — both LDS: the LDS unit performs one wave's operations in the order they were
+  // issued, so a sibling that reads the flag as 1 and then the values gets the values.  NO fence builtin here:
+  // a workgroup-scope fence orders every address space, i.e. it waits for vmcnt(0) and drains the corpus
+  // ring (it made each block of the parking phase twice as long, tools/trace_fused.py).
+  volatile float* tv = st->tauv;
+  if (lane < 32) {
+    tv[lane] = __builtin_bit_cast(float, (uint32_t)tq[0]);
+    tv[32 + lane] = __builtin_bit_cast(float, (uint32_t)tq[1]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) *(volatile uint32_t*)&st->tau_flag = 1u;
+  return true;
+}
+// any wave: the thresholds from LDS if wave 0 has published them
 template <int QH>
-__device__ __forceinline__ bool tau_wait(const FusedParams& p, float (&tau)[QH], int lane) {
-  unsigned long long tq[QH];
+__device__ __forceinline__ bool tau_from_lds(StageLds* st, float (&tau)[QH], int lane) {
+  if (*(volatile uint32_t*)&st->tau_flag == 0u) return false;
+  asm volatile("" ::: "memory");
+  volatile float* tv = st->tauv;
+#pragma unroll
+  for (int hq = 0; hq < QH; ++hq) tau[hq] = tv[hq * 32 + (lane & 31)];
+  return true;
+}
+// bounded wait (spill area exhausted, or nothing left to stream)
+template <int QH>
+__device__ __forceinline__ bool tau_wait(const FusedParams& p, StageLds* st, float (&tau)[QH], int lane, int wave) {
   for (uint32_t it = 0; it < p.wait_iters; ++it) {
-    tau_fetch<QH>(p, tq, lane);
-    if (tau_ready<QH>(p, tq, tau)) return true;
-    __builtin_amdgcn_s_sleep(64);
+    if (wave == 0 && *(volatile uint32_t*)&st->tau_flag == 0u) {
+      unsigned long long tq[2];
+      tau_fetch<QH>(p, tq, lane);
+      (void)tau_publish_lds(p, st, tq, lane);
+    }
+    if (tau_from_lds<QH>(st, tau, lane)) return true;
+    __builtin_amdgcn_s_sleep(32);
   }
   return false;
 }
 
+#if defined(TS_TUNING) && defined(FZ_TRACE)   // diagnostic builds only: per-wave phase time stamps (100 MHz)
+__device__ unsigned long long fz_trace_buf[4096 * 8];
+#define FZ_STAMP(row, i) do { if ((threadIdx.x & 63) == 0 && (row) < 4096) fz_trace_buf[(row) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int ts_debug_fused_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fz_trace_buf), sizeof(fz_trace_buf)) == hipSuccess ? 0 : -2;
+}
+#else
+#define FZ_STAMP(row, i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 // ---- threshold workgroups ---------------------------------------------------------------------
-__device__ void tau_role(const FusedParams& p, int tw, unsigned char* smem) {
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);    // [256]
-  uint32_t* wtot = hist + 256;                           // [4]
-  uint32_t* res = wtot + 8;                              // [0] digit, [1] rank left, [2] flags
-  uint32_t* keys = res + 8;                              // [expect]
+// ONE WAVE PER QUERY, no workgroup barrier and no LDS atomics: wave v of threshold workgroup t owns queries
+// t*tau_waves + v, +tau_wgs*tau_waves, ...  Its keys live in a private LDS region (lane L holds keys L, L+64, ...:
+// conflict-free reads); the m-th largest is found by BISECTION on the 32-bit key — count the keys >= pivot,
+// one wave reduction per step, the bits every key shares skipped.  (Tried before: a radix select by the whole
+// workgroup — ~20 barriers, 14 us per query pair; a radix select by one wave — bank-conflict-bound LDS atomics,
+// 25 us.  tools/trace_fused.py.)
+__device__ __forceinline__ void coherent_load4x8(const uint32_t* p0, int stride, uint32_t (&v)[8]) {
+  // eight independent agent-coherent dword loads in flight, then ONE wait
+  asm volatile(
+      "global_load_dword %0, %8, off sc0 sc1\n\t"
+      "global_load_dword %1, %9, off sc0 sc1\n\t"
+      "global_load_dword %2, %10, off sc0 sc1\n\t"
+      "global_load_dword %3, %11, off sc0 sc1\n\t"
+      "global_load_dword %4, %12, off sc0 sc1\n\t"
+      "global_load_dword %5, %13, off sc0 sc1\n\t"
+      "global_load_dword %6, %14, off sc0 sc1\n\t"
+      "global_load_dword %7, %15, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p0), "v"(p0 + stride), "v"(p0 + 2 * stride), "v"(p0 + 3 * stride), "v"(p0 + 4 * stride),
+        "v"(p0 + 5 * stride), "v"(p0 + 6 * stride), "v"(p0 + 7 * stride)
+      : "memory");
+}
+__device__ __forceinline__ void tau_role(const FusedParams& p, int tw, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t n = p.expect;
-  // the hint: all sample waves have reported (bounded; the loads below re-check slot by slot)
-  if (tid == 0) {
-    for (uint32_t it = 0; it < p.wait_iters; ++it) {
-      const uint32_t cur = __hip_atomic_load(p.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int32_t)(cur - p.arrive_goal) >= 0) break;
-      __builtin_amdgcn_s_sleep(64);
-    }
+  if (wave >= p.tau_waves) return;
+  const uint32_t n = p.expect;                            // (a multiple of 512: see the host side)
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * n;
+  const int trow = 3000 + tw * SCAN_WAVES + wave;
+  FZ_STAMP(trow, 0);
+  // the hint: all sample workgroups have reported (bounded; the loads below re-check slot by slot)
+  for (uint32_t it = 0; it < p.wait_iters; ++it) {
+    const uint32_t cur = __hip_atomic_load(p.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int32_t)(cur - p.arrive_goal) >= 0) break;
+    __builtin_amdgcn_s_sleep(48);   // (~1 us: 64 waves hammering one address with L2-bypassing loads disturb the stream)
   }
-  __syncthreads();
-  for (int q = tw; q < TS_MAX_Q; q += p.tau_wgs) {
+  FZ_STAMP(trow, 1);
+  const int first = tw * p.tau_waves + wave, step = p.tau_wgs * p.tau_waves;
+  for (int q = first; q < TS_MAX_Q; q += step) {
     if (q >= p.sp.nq) {   // no such query: nothing may pass
-      if (tid == 0)
+      if (lane == 0)
         __hip_atomic_store(p.tau64 + q, ((unsigned long long)p.gen << 32) | 0x7f7fffffull, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
     uint32_t* src = p.skeys + (size_t)q * p.keys_ld;
-    // ---- slots -> LDS, until every one of them holds a key
+    // ---- slots -> LDS until every one of them holds a key; the bits all keys share on the way
     bool complete = false;
+    uint32_t k_and = 0xFFFFFFFFu, k_or = 0u;
     for (uint32_t it = 0; it < p.wait_iters && !complete; ++it) {
-      __syncthreads();
-      if (tid == 0) res[2] = 0u;
-      __syncthreads();
       bool hole = false;
-      for (uint32_t i = 4 * tid; i < n; i += 4 * SCAN_THREADS) {   // (n is a multiple of 4: two slots per sample item, items even)
-        const u32x4 v = coherent_load16(src + i);
-        keys[i] = v[0]; keys[i + 1] = v[1]; keys[i + 2] = v[2]; keys[i + 3] = v[3];
-        hole |= (v[0] == 0u) | (v[1] == 0u) | (v[2] == 0u) | (v[3] == 0u);
-      }
-      if (__builtin_amdgcn_ballot_w64(hole) != 0ull && lane == 0) res[2] = 1u;
-      __syncthreads();
-      complete = res[2] == 0u;
-      if (!complete) __builtin_amdgcn_s_sleep(64);
-    }
-    uint32_t tkey = 0u;
-    if (complete) {
-      // ---- the m-th largest key: MSB-first radix select, 8 bits per pass, in LDS
-      uint32_t prefix = 0u, krem = p.m < n ? p.m : n;
-      int bits = 0;
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        __syncthreads();
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += SCAN_THREADS) {
-          const uint32_t key = keys[i];
-          if (bits == 0 || (key >> (32 - bits)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        // bin holding the krem-th largest: suffix sums over the 256 bins (4 waves x 64 lanes)
-        uint32_t own = 0u, v = 0u;
-        if (tid < 256) {
-          own = hist[tid];
-          v = own;
+      k_and = 0xFFFFFFFFu; k_or = 0u;
+      for (uint32_t i0 = 0; i0 < n; i0 += 512) {
+        uint32_t v[8];
+        coherent_load4x8(src + i0 + lane, 64, v);
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_down((int)v, o, 64);
-            if (lane + o < 64) v += t;
-          }
-          if (lane == 0) wtot[wave] = v;
+        for (int j = 0; j < 8; ++j) {
+          keys[i0 + 64 * j + lane] = v[j];
+          hole |= v[j] == 0u;
+          k_and &= v[j]; k_or |= v[j];
         }
-        __syncthreads();
-        if (tid < 256) {
-          for (int w2 = wave + 1; w2 < 4; ++w2) v += wtot[w2];   // entries in bins >= tid
-          const uint32_t above = v - own;
-          if (v >= krem && above < krem) { res[0] = (uint32_t)tid; res[1] = krem - above; }
-        }
-        __syncthreads();
-        prefix = (prefix << 8) | res[0];
-        krem = res[1];
-        bits += 8;
       }
-      tkey = prefix;
-      // give the slots back as zeros (the sample is complete: nobody writes them any more)
-      for (uint32_t i = 4 * tid; i < n; i += 4 * SCAN_THREADS) coherent_store16(src + i, u32x4{0u, 0u, 0u, 0u});
+      complete = __builtin_amdgcn_ballot_w64(hole) == 0ull;
+      if (!complete) __builtin_amdgcn_s_sleep(8);
     }
-    if (tid == 0) {
-      // scores >= the m-th largest group maximum pass.  No complete sample within the bound (e.g. the scan
-      // workgroups never became resident): nothing passes and the verification redoes the batch.
-      const uint32_t bits32 = complete ? __builtin_bit_cast(uint32_t, fz_unkey(tkey)) : 0x7f7fffffu;
+    if (q == first) FZ_STAMP(trow, 2);
+    uint32_t bits32 = 0x7f7fffffu;   // no complete sample within the bound: nothing passes, the verification redoes the batch
+    if (complete) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        k_and &= (uint32_t)__shfl_xor((int)k_and, o, 64);
+        k_or |= (uint32_t)__shfl_xor((int)k_or, o, 64);
+      }
+      wave_lds_sync();
+      // the largest T with  #{key >= T} >= m  is the m-th largest key: build it bit by bit from the first bit the
+      // keys disagree on (the bits above it are common to all of them)
+      const uint32_t want = p.m < n ? p.m : n;
+      const uint32_t diff = k_and ^ k_or;
+      uint32_t T = k_and;                                     // common leading bits (and zeros below them, filled in next)
+      if (diff) {
+        const int top = 31 - __builtin_clz(diff);
+        T = k_and & ~((2u << top) - 1u);                      // keep only the bits above the first disagreement
+        // 14 bits below the first disagreement are plenty (2^-14 of the sample's score spread); the bits left
+        // at zero make T a little LOWER than the m-th largest key, which is the safe side
+        const int last = top > 13 ? top - 13 : 0;
+        for (int b = top; b >= last; --b) {
+          const uint32_t cand = T | (1u << b);
+          uint32_t cnt = 0;
+          for (uint32_t i = lane; i < n; i += 512) {           // (n is a multiple of 512: eight LDS reads in flight)
+            uint32_t kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = keys[i + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cnt += kk[u] >= cand ? 1u : 0u;
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+          if (cnt >= want) T = cand;
+        }
+      }
+      bits32 = __builtin_bit_cast(uint32_t, fz_unkey(T));   // scores >= the m-th largest group maximum pass
+    }
+    if (lane == 0)
       __hip_atomic_store(p.tau64 + q, ((unsigned long long)p.gen << 32) | (unsigned long long)bits32, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
+    if (q == first) FZ_STAMP(trow, 3);
+    if (complete) {
+      // give the slots back as zeros (the sample is complete: nobody writes them any more)
+      for (uint32_t i = 4 * lane; i < n; i += 4 * 64) coherent_store16(src + i, u32x4{0u, 0u, 0u, 0u});
     }
   }
+  FZ_STAMP(trow, 4);
 }
 
 // ---- the kernel -------------------------------------------------------------------------------
@@ -313,17 +355,21 @@ __device__ __forceinline__ void build_qimage(const FusedParams& p, u32x4* qlds, 
 template <int DT, int QH>
 __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if ((int)blockIdx.x >= p.scan_wgs) {
-    tau_role(p, (int)blockIdx.x - p.scan_wgs, smem);
+  // The threshold workgroups come FIRST in the grid: they are dispatched before the scan workgroups and so always
+  // find a CU at once — in pipelined mode the previous search's select (64 workgroups, 128 KiB of LDS each) becomes
+  // runnable about when this kernel starts and would otherwise take the free CUs for its first 30 us.
+  if ((int)blockIdx.x < p.tau_wgs) {
+    tau_role(p, (int)blockIdx.x, smem);
     return;
   }
+  const int sblock = (int)blockIdx.x - p.tau_wgs;   // index among the scan workgroups
   u32x4* qlds = reinterpret_cast<u32x4*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int kg = p.sp.kg;
   const int64_t nwaves = (int64_t)p.scan_wgs * SCAN_WAVES;
-  const int64_t w = (int64_t)blockIdx.x * SCAN_WAVES + wave;
+  const int64_t w = (int64_t)sblock * SCAN_WAVES + wave;
   BlockOrder order;
   order.nblk = p.sp.nwork;
   order.stride = p.sample_stride;
@@ -334,10 +380,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   const int64_t my_rest = w < order.n_rest ? (order.n_rest - w + nwaves - 1) / nwaves : 0;
   const int64_t my_items = my_sample + my_rest;
   auto blk_of = [&](int64_t j) -> int64_t {
-    return j < my_sample ? (w + j * nwaves) * order.stride : rest_block(order, w + (j - my_sample) * nwaves);
+    return j < my_sample ? sample_block(order, w + j * nwaves) : rest_block(order, w + (j - my_sample) * nwaves);
   };
   const bool active = my_items > 0;
 
+  const int srow = w < 3000 ? (int)w : 1 << 20;
+  FZ_STAMP(srow, 0);
   // ---- the first corpus loads go out before anything else
   const u32x4* base = reinterpret_cast<const u32x4*>(p.sp.corpus) + lane;
   const size_t blk_units = (size_t)kg * 64;
@@ -354,23 +402,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   else if (p.q_dtype == TS_F16) build_qimage<_Float16, DT, QH>(p, qlds, tid);
   else build_qimage<__bf16, DT, QH>(p, qlds, tid);
   StageLds* st = reinterpret_cast<StageLds*>(smem + (size_t)kg * QH * 1024);
-  if (tid == 0) st->cnt = 0;
+  if (tid == 0) { st->cnt = 0; st->tau_flag = 0; st->arrived = 0; }
   // (the staging loop's loads sit under lane predicates: make the compiler's scoreboard forget them
   // here instead of in front of the first ring consumer)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
+  FZ_STAMP(srow, 1);
 
   bool failed = false;
   if (active) {
     float tau[QH];
 #pragma unroll
     for (int hq = 0; hq < QH; ++hq) tau[hq] = 3.402823466e38f;
-    unsigned long long tq[QH];
-    tau_fetch<QH>(p, tq, lane);          // first look, consumed after the first block
+    unsigned long long tq[2] = {0ull, 0ull};   // (wave 0 only: the last look at the published thresholds)
     bool filtering = false;
-    int64_t n_spilled = 0;               // items [0, n_spilled) were parked in the spill area
-    float* myspill = p.spill + (size_t)w * (TS_MAX_Q * 32);
-    const size_t spill_round = (size_t)nwaves * (TS_MAX_Q * 32);
+    f32x16 parkA[QH], parkB[QH];         // score tiles waiting for the thresholds
+    int64_t blkA = 0, blkB = 0;
+    int npark = 0;
     const u32x4* ql = qlds + lane;
 
     for (int64_t j = 0; j < my_items; ++j) {
@@ -394,6 +442,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // (still parking tiles: look at the thresholds now — the answer is consumed one ring's worth of MFMAs
+      // later, ~2 us, instead of a whole block later)
+      if (!filtering && wave == 0) tau_fetch<QH>(p, tq, lane);
 #pragma unroll
       for (int i = 0; i < TS_RING; ++i) {
 #pragma unroll
@@ -415,40 +466,58 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
             __hip_atomic_store(p.skeys + (size_t)q * p.keys_ld + slot, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        if (j + 1 == my_sample && lane == 0) atomicAdd(p.arrive, 1u);   // (a hint; see tau_role)
+        // the arrival hint (see tau_role): ONE global atomic per workgroup, by its last wave to get here
+        if (j + 1 == my_sample && lane == 0 && atomicAdd(&st->arrived, 1u) == SCAN_WAVES - 1) atomicAdd(p.arrive, 1u);
       }
-      if (!filtering) filtering = tau_ready<QH>(p, tq, tau);
-      if (!filtering && j >= p.spill_rounds) {
-        // spill area exhausted: the only place a wave waits in mid-stream
-        filtering = tau_wait<QH>(p, tau, lane);
-        if (!filtering) { failed = true; break; }
+      if (j == 0) FZ_STAMP(srow, 2);
+      if (j == 1) FZ_STAMP(srow, 7);
+      if (!filtering) {
+        if (wave == 0) (void)tau_publish_lds(p, st, tq, lane);
+        filtering = tau_from_lds<QH>(st, tau, lane);
+        if (!filtering && npark == 2) {
+          // two tiles parked and a third one ready: the only place a wave waits in mid-stream
+          filtering = tau_wait<QH>(p, st, tau, lane, wave);
+          if (!filtering) { failed = true; break; }
+        }
+        if (filtering) {
+          FZ_STAMP(srow, 3);
+          if (npark >= 1) epilogue_filter<QH>(p.sp, st, parkA, tau, blkA, lane);
+          if (npark == 2) epilogue_filter<QH>(p.sp, st, parkB, tau, blkB, lane);
+          npark = 0;
+        }
       }
       if (filtering) {
         epilogue_filter<QH>(p.sp, st, acc, tau, blk, lane);
+      } else if (npark == 0) {
+#pragma unroll
+        for (int hq = 0; hq < QH; ++hq) parkA[hq] = acc[hq];
+        blkA = blk;
+        npark = 1;
       } else {
-        spill_store<QH>(myspill + (size_t)j * spill_round, acc, lane);
-        n_spilled = j + 1;
-        tau_fetch<QH>(p, tq, lane);      // next look, consumed after the next block
+#pragma unroll
+        for (int hq = 0; hq < QH; ++hq) parkB[hq] = acc[hq];
+        blkB = blk;
+        npark = 2;
       }
       blk = blkn;
       cur = nxt;
     }
+    FZ_STAMP(srow, 4);
     if (!failed && !filtering) {
-      filtering = tau_wait<QH>(p, tau, lane);
+      filtering = tau_wait<QH>(p, st, tau, lane, wave);
       failed = !filtering;
-    }
-    if (!failed) {
-      // the parked tiles, now that the thresholds are known
-      for (int64_t j = 0; j < n_spilled; ++j) {
-        f32x16 acc[QH];
-        spill_load<QH>(myspill + (size_t)j * spill_round, acc, lane);
-        epilogue_filter<QH>(p.sp, st, acc, tau, blk_of(j), lane);
+      FZ_STAMP(srow, 3);
+      if (filtering) {
+        if (npark >= 1) epilogue_filter<QH>(p.sp, st, parkA, tau, blkA, lane);
+        if (npark == 2) epilogue_filter<QH>(p.sp, st, parkB, tau, blkB, lane);
       }
     }
   }
+  FZ_STAMP(srow, 5);
   if (__builtin_amdgcn_ballot_w64(failed) != 0ull && lane == 0)
     atomicOr(&p.sp.cand_cnt[0], 0x80000000u);   // "overflow": ts_index.hip redoes this batch exactly
   flush_stage(p.sp, st, tid);
+  FZ_STAMP(srow, 6);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -469,9 +538,6 @@ static int launch_fused_t(const FusedParams& p, int grid, size_t lds, hipStream_
 }
 
 size_t ts_fused_keys_bytes() { return (size_t)TS_MAX_Q * TS_FUSED_MAX_KEYS * sizeof(uint32_t); }
-size_t ts_fused_spill_bytes(int scan_wgs, int spill_rounds) {
-  return (size_t)spill_rounds * scan_wgs * SCAN_WAVES * TS_MAX_Q * 32 * sizeof(float);
-}
 
 int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t stream) {
   FusedParams p{};
@@ -495,7 +561,6 @@ int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t
   p.scan_wgs = a.scan_wgs;
   p.tau_wgs = a.tau_wgs;
   p.n_sample = a.n_sample;
-  p.spill_rounds = a.spill_rounds;
   p.sample_stride = a.sample_stride;
   p.m = a.m;
   p.expect = a.expect;
@@ -506,11 +571,18 @@ int ts_launch_fused(const TsLayout& L, int qh, const TsFusedArgs& a, hipStream_t
   p.keys_ld = TS_FUSED_MAX_KEYS;
   p.arrive = a.arrive;
   p.tau64 = a.tau64;
-  p.spill = a.spill;
   // every workgroup gets the same dynamic LDS: the scan's query image + staging, or the threshold role's keys
-  const size_t lds = std::max(ts_scan_lds_bytes(L, qh), (size_t)a.expect * 4 + 4096);
-  if (a.expect > TS_FUSED_MAX_KEYS || (a.expect & 3u) || lds > 160 * 1024 || a.expect != 2 * a.n_sample ||
-      a.n_sample * a.sample_stride > a.nblk || a.n_sample < 1 || a.sample_stride < 1) {
+  // threshold role: every wave that takes queries keeps its keys + a 256-bin histogram in LDS
+  const size_t per_wave = (size_t)a.expect * 4;
+  int tau_waves = (int)std::min<size_t>(SCAN_WAVES, (160 * 1024) / per_wave);
+  if (tau_waves < 1) { ts_set_error("one-launch search: sample too large for LDS"); return TS_ERR_INVALID; }
+  // (no more workgroups x waves than queries; at least enough to leave each wave one or two queries)
+  while (tau_waves > 1 && (a.tau_wgs * (tau_waves - 1)) >= TS_MAX_Q) --tau_waves;
+  p.tau_waves = tau_waves;
+  const size_t lds = std::max(ts_scan_lds_bytes(L, qh), per_wave * tau_waves);
+  if (a.expect > TS_FUSED_MAX_KEYS || (a.expect & 511u) || lds > 160 * 1024 || a.expect != 2 * a.n_sample ||
+      (a.n_sample % SAMPLE_GROUP) != 0 || (a.n_sample / SAMPLE_GROUP) * a.sample_stride > a.nblk ||
+      a.n_sample < SAMPLE_GROUP || a.sample_stride < SAMPLE_GROUP) {
     ts_set_error("one-launch search: bad sample geometry (%u slots)", a.expect);
     return TS_ERR_INVALID;
   }

@@ -89,6 +89,7 @@ constexpr int64_t kSampleDiv = 128;         // sample >= N/128 rows
 constexpr uint32_t kMinSampleRank = 24;
 constexpr uint32_t kOversample = 4;         // expected candidates ~ 4k per query
 constexpr int64_t kDenseChunkRows = 1 << 20;
+constexpr int64_t kOneLaunchMaxRows = 4 << 20;   // default use of the one-launch search (search_pass_on)
 constexpr int kHeadStartUs = 12;           // pipelined mode: delay of the select behind the next scan (search_pass)
 
 }  // namespace
@@ -492,15 +493,17 @@ static int ensure_streams(ts_index* h) {
 // workspace sets; a set is reused only after the Sel that last read it (its ev_sel).
 // ---- geometry of the one-launch search
 struct FusedPlan {
-  int scan_wgs, tau_wgs, spill_rounds;
+  int scan_wgs, tau_wgs;
   int64_t n_sample, sample_stride, sample_rows;
   uint32_t m, expect, sample_waves;
 };
 static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool pipe, FusedPlan* fp) {
-  // pipelined: the scan leaves a quarter of the CUs to its neighbours' select (64 workgroups that cannot
-  // share a CU with a scan workgroup: they always fit, whatever is placed first) and to the exchange;
-  // otherwise an eighth (the kernel is HBM-bound: 224 CUs stream as fast as 256, tools/cus.sh)
-  int scan_wgs = pipe ? h->num_cus - h->num_cus / 4 : h->num_cus - h->num_cus / 8;
+  // the scan takes 7/8 of the CUs (the kernel is HBM-bound: 224 CUs stream as fast as 256, tools/cus.sh); the
+  // threshold workgroups, and in pipelined mode the neighbours' select and the exchange, use the rest.  The next
+  // search's kernel follows on the SAME stream, so its workgroups are dispatched the moment this one ends, ahead
+  // of the select that waits for this kernel through an event on another stream: no placement race.
+  (void)pipe;
+  int scan_wgs = h->num_cus - h->num_cus / 8;
 #ifdef TS_TUNING
   static const int dbg_cus = getenv("TS_SCAN_CUS") ? atoi(getenv("TS_SCAN_CUS")) : 0;
   if (dbg_cus > 0) scan_wgs = dbg_cus;
@@ -513,8 +516,13 @@ static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool p
   int64_t R = (want_rows + nwaves * TS_ROWS_PER_BLOCK - 1) / (nwaves * TS_ROWS_PER_BLOCK);
   R = std::max<int64_t>(1, std::min<int64_t>(R, 16));
   int64_t n_sample = std::min(nblk, R * nwaves);
-  n_sample = std::min<int64_t>(n_sample, TS_FUSED_MAX_KEYS / 2) & ~(int64_t)1;   // two slots per block, slots a multiple of 4
-  const int64_t stride = std::max<int64_t>(1, nblk / n_sample);
+  n_sample = std::min<int64_t>(n_sample, TS_FUSED_MAX_KEYS / 2) & ~(int64_t)255;   // two slots per block; groups of 8 blocks;
+  if (n_sample < 256) return false;                                                 // slots a multiple of 512
+  int64_t stride = nblk / (n_sample / 8);                   // between the first blocks of consecutive 8-block groups (>= 8)
+#ifdef TS_TUNING   // experiment: the sample is the first n_sample blocks of the corpus (biased for grouped corpora)
+  static const bool dbg_prefix = getenv("TS_FUSED_PREFIX_SAMPLE") != nullptr;
+  if (dbg_prefix) stride = 8;
+#endif
   const int64_t rows = n_sample * TS_ROWS_PER_BLOCK;
   const int64_t oversample = k > 1024 ? 3 : kOversample;
   uint32_t m = (uint32_t)((oversample * (int64_t)k * rows + N - 1) / N);
@@ -524,12 +532,11 @@ static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool p
   fp->scan_wgs = scan_wgs;
   fp->tau_wgs = tau_wgs;
   fp->n_sample = n_sample;
-  fp->spill_rounds = (int)((n_sample + nwaves - 1) / nwaves) + 4;
   fp->sample_stride = stride;
   fp->sample_rows = rows;
   fp->m = m;
   fp->expect = expect;
-  fp->sample_waves = (uint32_t)std::min(nwaves, n_sample);
+  fp->sample_waves = (uint32_t)std::min<int64_t>(scan_wgs, n_sample / 8);   // WORKGROUPS that report: one arrival each
   return true;
 }
 
@@ -604,12 +611,20 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   // ---- one-launch search (ts_fused.hip) whenever its threshold estimate is valid: the sample's 16-row
   // group maxima stand in for the scores, which holds while the wanted rank is far below the group count
   FusedPlan fp{};
-  const bool fused = filter && !(flags & TS_FLAG_CLASSIC) && plan_fused(h, N, nblk, k, pipe, &fp);
+  // Where it is taken by default: unpipelined searches of up to kOneLaunchMaxRows rows, the regime in which the three
+  // launches it removes are a visible share of the batch (1.25 M x 768: 0.343 vs 0.359 ms per batch back to back,
+  // 0.376 vs 0.391 synchronous).  At 10 M rows both paths take 2.27 ms and the plain scan kernel is the cleaner
+  // roofline object; pipelined (TS_FLAG_PIPELINE) the five-launch path already hides its preparation under the
+  // previous scan and is 3 % ahead (0.335 vs 0.345 ms with the exchange).  TS_FLAG_ONE_LAUNCH forces it anywhere.
+  const bool want_fused = (flags & TS_FLAG_ONE_LAUNCH) || (!pipe && N <= kOneLaunchMaxRows);
+  const bool fused = filter && !(flags & TS_FLAG_CLASSIC) && want_fused && plan_fused(h, N, nblk, k, pipe, &fp);
   // (the one-launch search has no preparation phase: what remains of "P" rides on the scan stream)
   hipStream_t sP = pipe ? (fused ? h->s_scan : h->s_pro) : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
   // the set may still be in use on the GPU by the (asynchronous) search that had it last, possibly
   // on another stream
-  if (W.used) TS_HIP(hipStreamWaitEvent(sP, W.ev_sel, 0));
+  // (asked first whether that search is already over — with four sets in rotation it normally is: a wait on
+  // another stream's event in front of every scan, even a satisfied one, costs the scan stream 10-20 us)
+  if (W.used && hipEventQuery(W.ev_sel) != hipSuccess) TS_HIP(hipStreamWaitEvent(sP, W.ev_sel, 0));
   // the output buffers may be memory the caller's stream is still reading (a recycled
   // allocation): the final phase must not start before the stream's work issued so far
   if (pipe) TS_HIP(hipEventRecord(W.ev_in, s));
@@ -641,7 +656,6 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
       TS_CHECK(ensure(W.hist, ts_fused_keys_bytes()));
       W.hist_dirty = true;
     }
-    TS_CHECK(ensure(W.spill, ts_fused_spill_bytes(fp.scan_wgs, fp.spill_rounds)));
     if (W.hist_dirty) {
       TS_HIP(hipMemsetAsync(W.hist.p, 0, ts_fused_keys_bytes(), sS));
       TS_HIP(hipMemsetAsync(W.cand_cnt(), 0, 256, sS));
@@ -659,7 +673,6 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     a.scan_wgs = fp.scan_wgs;
     a.tau_wgs = fp.tau_wgs;
     a.n_sample = fp.n_sample;
-    a.spill_rounds = fp.spill_rounds;
     a.sample_stride = fp.sample_stride;
     a.m = fp.m;
     a.expect = fp.expect;
@@ -669,7 +682,6 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     a.skeys = (uint32_t*)W.hist.p;
     a.arrive = W.arrive();
     a.tau64 = W.tau64();
-    a.spill = (float*)W.spill.p;
     a.cand_cnt = W.cand_cnt();
     a.cand_score = (float*)W.cand_score.p;
     a.cand_id = (int32_t*)W.cand_id.p;

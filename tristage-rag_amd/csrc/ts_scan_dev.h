@@ -96,7 +96,10 @@ __device__ __forceinline__ void epilogue_dense(const ScanParams& p,
 #define STAGE_CAP 2048
 struct StageLds {
   uint32_t cnt;
-  uint32_t pad[3];
+  uint32_t tau_flag;        // ts_fused.hip: wave 0 has published this launch's thresholds in tauv[]
+  uint32_t arrived;         // ts_fused.hip: waves of this workgroup that have delivered their sample
+  uint32_t pad[1];
+  float tauv[TS_MAX_Q];     // ts_fused.hip: the thresholds, once tau_flag is set
   uint32_t qcnt[TS_MAX_Q];
   uint32_t qbase[TS_MAX_Q];
   uint32_t qoff[TS_MAX_Q];

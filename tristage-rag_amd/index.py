@@ -75,6 +75,7 @@ class FlatIPIndex:
         self._auto_redone = []  # tickets repeated by an internal finish() the caller has not seen yet
         self.auto_finish = True  # False: the owner (ShardedFlatIPIndex) calls finish() itself, collectively
         self.classic_filter = False  # True: every search takes the five-launch filter path (A/B measurements)
+        self.one_launch_filter = False  # True: the one-launch scan wherever it is valid (also pipelined / large corpora)
 
     # -- lifetime ---------------------------------------------------------
     def close(self) -> None:
@@ -131,7 +132,7 @@ class FlatIPIndex:
         return None
 
     def search(self, q, k: int, exact_dense: bool = False, async_: bool = False, out=None,
-               inputs_ready: bool = False, classic: bool = False):
+               inputs_ready: bool = False, classic: bool = False, one_launch: bool = False):
         """Top-``k`` inner products.  numpy in -> ``(D float32[B,k], I int64[B,k])``
         numpy out (FAISS convention, -1 padded); CUDA tensor in -> tensors out.
 
@@ -148,8 +149,10 @@ class FlatIPIndex:
         if k <= 0:
             raise ValueError("k must be positive")
         flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
-        if classic or self.classic_filter:   # the five-launch filter path even where the one-launch scan applies (A/B, tests)
+        if classic or self.classic_filter:   # the five-launch filter path even where the one-launch scan is the default (A/B, tests)
             flags |= _lib.TS_FLAG_CLASSIC
+        elif one_launch or self.one_launch_filter:   # the one-launch scan also where it is not the default
+            flags |= _lib.TS_FLAG_ONE_LAUNCH
         if async_:
             if not (_is_tensor(q) and q.is_cuda):
                 raise ValueError("async_ search needs a CUDA tensor")
