@@ -117,14 +117,6 @@ __device__ __forceinline__ int m16_len(const Ms16Params& p, int d) {
 __device__ __forceinline__ int m16_tiles(int len) {
   return len > 0 ? min((len + 31) / 32, 1 << 18) : 0;
 }
-// The unit of WORK DISTRIBUTION is half a tile (16 token rows): a wave's slice may begin or end in the middle
-// of a 32-row MFMA tile.  Lanes whose row falls outside the wave's part of the tile read a row inside it
-// instead (a duplicate cannot change a maximum, and the duplicate loads coalesce with the real ones), so a
-// half tile costs half the HBM bytes.  With whole tiles a 1000-candidate query gave 1024 waves 4.4 tiles
-// each on average and 5 to two fifths of them: the launch took 5 tile times, not 4.4.
-__device__ __forceinline__ int m16_units(int len) {
-  return len > 0 ? min((len + 15) / 16, 1 << 19) : 0;
-}
 // float -> uint whose unsigned order is the float order; 0 is below every finite value
 __device__ __forceinline__ uint32_t m16_key(float f) {
   const uint32_t b = __float_as_uint(f);
@@ -322,7 +314,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   int mytiles = 0;
   for (int d = d0; d < d1; ++d) {
     const int len = m16_len(p, d);
-    mytiles += m16_units(len);
+    mytiles += m16_tiles(len);
     if (len <= 0 && blockIdx.x == 0 && blockIdx.y == 0)
       p.out[d] = 0.f;  // reference: a candidate that cannot be scored keeps 0.0 (:285-291)
   }
@@ -351,7 +343,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     for (int d = d0; d < d1; ++d) {
       prefix[d] = run;
       const int len = m16_len(p, d);  // (L1/L2 hit: read a moment ago)
-      run += m16_units(len);
+      run += m16_tiles(len);
     }
     if (tid == 0) prefix[p.n_docs] = T;
   }
@@ -365,7 +357,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
   const bool has_work = lo < hi;   // (a wave without tiles still stages its share of the query image)
 
-  int doc = 0, unit = 0, len = 1;   // position: half-tile `unit` of candidate `doc`
+  int doc = 0, tile = 0, len = 1;
   int64_t start = 0;
   if (has_work) {
     int a = 0, b = p.n_docs;  // prefix[a] <= lo < prefix[b]
@@ -374,19 +366,15 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
       if ((int64_t)prefix[m] <= lo) a = m; else b = m;
     }
     doc = __builtin_amdgcn_readfirstlane(a);
-    unit = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
+    tile = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
     len = m16_len_s(p, doc);
     start = m16_start_s(p, doc);
   }
   const unsigned char* cur = p.docs;
   u32x4 ring[M16_RING];
-  // this wave's part of the tile that holds `unit`: `take` half tiles (1 or 2), token rows [r0, r1) of the tile
-  int take = 1;
   if (has_work) {
-    const int tl = unit >> 1;
-    take = (int)min((int64_t)(min(2 * tl + 2, m16_units(len)) - unit), hi - lo);
-    const int r0 = (unit & 1) * 16, r1 = min(len - tl * 32, (unit + take - 2 * tl) * 16);
-    cur = p.docs + ((size_t)(start + tl * 32 + min(max(r, r0), r1 - 1)) * H + 16 * h);
+    const int rows = min(32, len - tile * 32);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
 #pragma unroll
     for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
   }
@@ -451,27 +439,23 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   int nrec = 0, rdoc = 0;
   uint32_t rtiles = 0, rneed = 0, run_tiles = 0;
   uint32_t sink = 0;        // folds the words returned by this wave's atomicMax (see m16_flush_records)
-  bool from_start = (unit == 0);   // this wave has seen the current candidate from its first row on
+  bool from_start = (tile == 0);   // this wave has seen the current candidate from its first tile on
 
-  for (int64_t it = lo; it < hi;) {
+  for (int64_t it = lo; it < hi; ++it) {
     // ---- next item of the slice (wave-uniform)
-    const int64_t left = hi - it - take;          // half tiles of the slice after this item
-    const bool has_next = left > 0;
-    const bool to_end = unit + take >= m16_units(len);   // the candidate's last row is in this item
-    int ndoc = doc, nunit = unit + take, nlen = len, ntake = 1;
+    const bool has_next = it + 1 < hi;
+    int ndoc = doc, ntile = tile + 1, nlen = len;
     int64_t nstart = start;
-    if (has_next && to_end) {
-      nunit = 0;
+    if (has_next && ntile >= m16_tiles(len)) {
+      ntile = 0;
       ndoc = __builtin_amdgcn_readfirstlane(ndoc);
-      do { ++ndoc; nlen = m16_len_s(p, ndoc); } while (nlen <= 0);  // a later unit exists: terminates
+      do { ++ndoc; nlen = m16_len_s(p, ndoc); } while (nlen <= 0);  // a later tile exists: terminates
       nstart = m16_start_s(p, ndoc);
     }
     const unsigned char* nxt = cur;
     if (has_next) {
-      const int tl = nunit >> 1;
-      ntake = (int)min((int64_t)(min(2 * tl + 2, m16_units(nlen)) - nunit), left);
-      const int r0 = (nunit & 1) * 16, r1 = min(nlen - tl * 32, (nunit + ntake - 2 * tl) * 16);
-      nxt = p.docs + ((size_t)(nstart + tl * 32 + min(max(r, r0), r1 - 1)) * H + 16 * h);
+      const int nrows = min(32, nlen - ntile * 32);
+      nxt = p.docs + ((size_t)(nstart + ntile * 32 + min(r, nrows - 1)) * H + 16 * h);
     }
 
     f32x16 acc[NQT];
@@ -524,11 +508,12 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    run_tiles += (uint32_t)take;
+    ++run_tiles;
     if (it == lo) M16_STAMP(5);
 
     // ---- leaving this candidate (or the slice)
     if (!has_next || ndoc != doc) {
+      const bool to_end = tile + 1 >= m16_tiles(len);   // its last tile was this wave's
       if (from_start && to_end && p.passes == 1) {
         // The whole candidate went through THIS wave: its maxima are complete in registers — score it
         // here, no scratch, no atomics.  Same values and the same summation tree as m16_finish_doc (lane L
@@ -574,7 +559,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
         if (lane == nrec) {
           rdoc = doc;
           rtiles = run_tiles;
-          rneed = (uint32_t)p.passes * (uint32_t)m16_units(len);
+          rneed = (uint32_t)p.passes * (uint32_t)m16_tiles(len);
         }
         if (++nrec == 64) {  // (only with very many tiny candidates per wave)
           m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane, sink);
@@ -582,11 +567,9 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
         }
       }
       run_tiles = 0;
-      from_start = true;   // the next candidate (if any) starts at its first row
+      from_start = true;   // the next candidate (if any) starts at its tile 0
     }
-    doc = ndoc; unit = nunit; len = nlen; start = nstart; cur = nxt;
-    it += take;
-    take = ntake;
+    doc = ndoc; tile = ntile; len = nlen; start = nstart; cur = nxt;
   }
   M16_STAMP(6);
   if (nrec) m16_flush_records(p, nrec, rdoc, rtiles, rneed, lane, sink);
