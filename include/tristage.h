@@ -162,7 +162,9 @@ int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t r
  * New for the row-sharded multi-GPU path: `scores`/`ids` are
  * device arrays [nlists, nq, k] (e.g. the output of an RCCL all-gather of each
  * rank's ts_index_search result); writes the global top-k [nq, k] in the same
- * canonical order.  Entries with id < 0 are padding and ignored.            */
+ * canonical order.  Entries with id < 0 are padding and ignored.  k <= 8192;
+ * any number of lists (more than 16384 / k of them are merged in groups, then the
+ * groups' results: the order is total, so the result is the same).            */
 int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
                   int32_t nq, int32_t k, float* out_scores, int64_t* out_ids,
                   int32_t device, void* stream);

@@ -196,3 +196,28 @@ def test_sharded_async_repairs_survive_many_pending_batches():
         assert len(redone) == 35, redone
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R,k,B", [(20, 1000, 5), (9, 2048, 3), (33, 700, 2)])
+def test_merge_of_more_lists_than_fit_one_workgroup(R, k, B):
+    """nlists * k above the 16384 keys one workgroup selects among in LDS (e.g. 9 ranks x k = 2048): the lists are
+    merged in groups, then the groups' results — same canonical result as the oracle's merge, duplicated scores
+    across lists and padding entries included."""
+    import torch
+    from oracle import oracle
+    from tristage_rag_amd.index import merge_topk
+    rng = np.random.default_rng(R * 1000 + k)
+    pool = np.round(rng.standard_normal(4000), 2).astype(np.float32)           # many exact score ties
+    scores = np.empty((R, B, k), dtype=np.float32)
+    ids = np.empty((R, B, k), dtype=np.int64)
+    for r in range(R):
+        for b in range(B):
+            n_valid = k if (r + b) % 5 else k - 37                               # some lists end in padding
+            sc = np.sort(rng.choice(pool, size=n_valid))[::-1]
+            idv = rng.choice(10_000_000, size=n_valid, replace=False).astype(np.int64) + r * 10_000_000
+            order = np.lexsort((idv, -sc))                                      # canonical order inside a list
+            scores[r, b, :n_valid], ids[r, b, :n_valid] = sc[order], idv[order]
+            scores[r, b, n_valid:], ids[r, b, n_valid:] = -3.4028234663852886e38, -1
+    D0, I0 = oracle.merge_topk(scores, ids, k)
+    D, I = merge_topk(torch.from_numpy(scores).cuda(), torch.from_numpy(ids).cuda())
+    assert np.array_equal(I.cpu().numpy(), I0) and np.array_equal(D.cpu().numpy(), D0)

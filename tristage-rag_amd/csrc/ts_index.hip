@@ -1081,20 +1081,9 @@ extern "C" int ts_selftest_device_once(int32_t n_threads, int32_t n_devices) {
 }
 
 // ------------------------------------------------------------------ merge
-static int merge_impl(const float* scores, const int64_t* ids, int32_t nlists, int32_t nq, int32_t k,
+static int merge_once(const float* scores, const int64_t* ids, int32_t nlists, int32_t nq, int32_t k,
                       int64_t score_list_stride, int64_t id_list_stride, float* out_scores,
-                      int64_t* out_ids, int32_t device, void* stream) {
-  if (!scores || !ids || !out_scores || !out_ids || nlists <= 0 || nq < 0 || k <= 0) {
-    ts_set_error("bad arguments to merge");
-    return TS_ERR_INVALID;
-  }
-  if (nq == 0) return TS_OK;
-  if ((int64_t)nlists * k > TS_SEL_LDS_KEYS) {
-    ts_set_error("merge: nlists*k = %lld exceeds %d", (long long)nlists * k, TS_SEL_LDS_KEYS);
-    return TS_ERR_UNSUPPORTED;
-  }
-  DeviceGuard g(device);
-  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+                      int64_t* out_ids, void* stream) {
   SelParams p{};
   p.mode = SEL_MERGE64;
   p.scores = scores;
@@ -1108,8 +1097,53 @@ static int merge_impl(const float* scores, const int64_t* ids, int32_t nlists, i
   p.out_scores = out_scores;
   p.out_ids64 = out_ids;
   p.out_stride = k;
-  TS_CHECK(ts_launch_select(p, nq, (hipStream_t)stream));
-  return TS_OK;
+  return ts_launch_select(p, nq, (hipStream_t)stream);
+}
+
+static int merge_impl(const float* scores, const int64_t* ids, int32_t nlists, int32_t nq, int32_t k,
+                      int64_t score_list_stride, int64_t id_list_stride, float* out_scores,
+                      int64_t* out_ids, int32_t device, void* stream) {
+  if (!scores || !ids || !out_scores || !out_ids || nlists <= 0 || nq < 0 || k <= 0) {
+    ts_set_error("bad arguments to merge");
+    return TS_ERR_INVALID;
+  }
+  if (nq == 0) return TS_OK;
+  if (k > TS_SEL_LDS_KEYS / 2) {
+    ts_set_error("merge: k = %d exceeds %d", k, TS_SEL_LDS_KEYS / 2);
+    return TS_ERR_UNSUPPORTED;
+  }
+  DeviceGuard g(device);
+  if (!g.ok) { ts_set_error("hipSetDevice(%d) failed", device); return TS_ERR_HIP; }
+  if ((int64_t)nlists * k <= TS_SEL_LDS_KEYS)
+    return merge_once(scores, ids, nlists, nq, k, score_list_stride, id_list_stride, out_scores, out_ids, stream);
+  // More entries per query than one workgroup selects among in LDS (e.g. 16 ranks x k = 2048): merge the lists
+  // in groups that fit, then merge the groups' results — the order (score desc, id asc) is total, so merging is
+  // associative and the result is the same.  Rare, so the intermediate lists are allocated on the spot.
+  const int per = TS_SEL_LDS_KEYS / k;                    // lists per group (>= 2)
+  const int ngroups = (nlists + per - 1) / per;
+  float* ts = nullptr;
+  int64_t* ti = nullptr;
+  const size_t cells = (size_t)ngroups * nq * k;
+  if (hipMalloc((void**)&ts, cells * 4) != hipSuccess || hipMalloc((void**)&ti, cells * 8) != hipSuccess) {
+    if (ts) (void)hipFree(ts);
+    ts_set_error("merge: cannot allocate %zu bytes of intermediate lists", cells * 12);
+    return TS_ERR_OOM;
+  }
+  int st = TS_OK;
+  for (int gi = 0; gi < ngroups && st == TS_OK; ++gi) {
+    const int l0 = gi * per, nl = std::min(per, nlists - l0);
+    st = merge_once(scores + (size_t)l0 * score_list_stride, ids + (size_t)l0 * id_list_stride, nl, nq, k,
+                    score_list_stride, id_list_stride, ts + (size_t)gi * nq * k, ti + (size_t)gi * nq * k, stream);
+  }
+  if (st == TS_OK)
+    st = merge_impl(ts, ti, ngroups, nq, k, (int64_t)nq * k, (int64_t)nq * k, out_scores, out_ids, device, stream);
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && st == TS_OK) {
+    ts_set_error("merge: stream synchronisation failed");
+    st = TS_ERR_HIP;
+  }
+  (void)hipFree(ts);
+  (void)hipFree(ti);
+  return st;
 }
 
 extern "C" int ts_merge_topk(const float* scores, const int64_t* ids, int32_t nlists,
