@@ -133,6 +133,34 @@ def _pipeline_worker(rank, world, port, out_dir):
             res.append([r["doc_id"] for r in a["results"]])
         again = par.search("gpu memory d7")            # the per-candidate collectives are back in place
         assert [r["doc_id"] for r in again["results"]] == res[1]
+        # the array path over the ranks: token store + cached stage-3 token ids on every rank, stages 2/3 split by
+        # query, ONE gather of four small arrays per rank
+        from doubles import oracle_maxsim_indexed, oracle_maxsim_indexed_batch
+
+        def build_arrays(cls):
+            p = build(cls)
+            p.config.stage2_precompute_document_embeddings = True
+            p.config.stage3_cache_document_tokens = True
+            p.stage2 = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=9,
+                                                  precompute_document_embeddings=True),
+                                     maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed,
+                                     maxsim_indexed_batch_fn=oracle_maxsim_indexed_batch)
+            return p
+        par2, single2 = build_arrays(ShardedRetrievalPipeline), build_arrays(RetrievalPipeline)
+        par2._merge_fn = oracle_merge
+        par2.add_documents(docs)
+        single2.add_documents(docs)
+        assert par2.stage3._pairs_usable and len(par2.stage2.token_store) == len(docs)
+        took = []
+        orig = par2._search_many_arrays_sharded
+        par2._search_many_arrays_sharded = lambda *a, **k: (lambda r: (took.append(r is not None), r)[1])(orig(*a, **k))
+        many2, ref2 = par2.search_many(qs), single2.search_many(qs)
+        assert took == [True]
+        for a, b in zip(many2, ref2):
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
+                np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+            res.append([r["doc_id"] for r in a["results"]])
         json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()

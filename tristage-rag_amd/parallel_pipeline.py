@@ -144,6 +144,9 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         if not queries:
             return []
         n, R, rank = len(queries), self.world_size, self.rank
+        fast = self._search_many_arrays_sharded(queries, top_k)
+        if fast is not None:
+            return fast
         total_start = self._now()
         t = self._now()
         s1 = self.stage1.search_many(queries, self.config.stage1_top_k)
@@ -166,3 +169,52 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         t3 = max((g[3] or 0.0) for g in gathered) * len(mine) / n if t3 is not None else None
         total = (time.time() - total_start) / n if total_start else None
         return self._assemble_many(queries, top_k, s1, s2, s3, t1, t2, t3, total)
+
+    def _search_many_arrays_sharded(self, queries: List[str], top_k: int):
+        """The array path of RetrievalPipeline.search_many over R ranks: stage 1 collective (id / score matrices of
+        ALL queries on every rank), stages 2 and 3 of queries r, r+R, ... on rank r, then ONE all-gather of four small
+        arrays per rank instead of pickled record lists.  Every rank must reach the same decision (array path or
+        not): the preconditions are properties of the replicated stores, and a rank-local failure afterwards is
+        agreed on through the gather itself."""
+        import time
+        ready = self._arrays_ready()
+        flags: List[Any] = [None] * self.world_size
+        self._dist.all_gather_object(flags, bool(ready), group=self.group)
+        if not all(flags):
+            return None
+        n, R, rank = len(queries), self.world_size, self.rank
+        total_start = t = self._tick()
+        got = self._arrays_stage1(queries)          # collective inside (ShardedFlatIPIndex.search)
+        t1 = (self._tick() - t) / n if t is not None else None
+        mine = list(range(rank, n, R))
+        later = None
+        if got is not None and mine:
+            import torch
+            ids1_dev, sc1 = got
+            sel = torch.as_tensor(mine, device=ids1_dev.device)
+            later = self._arrays_stage23([queries[i] for i in mine], ids1_dev[sel])
+        payload = None if got is None or (mine and later is None) else (later if mine else ())
+        gathered: List[Any] = [None] * R
+        self._dist.all_gather_object(gathered, payload, group=self.group)
+        if any(g is None for g in gathered):
+            return None                              # some rank could not take the array path: all take the record path
+        import numpy as np
+        first = next(g for g in gathered if g)
+        pos2 = np.zeros((n,) + first[0].shape[1:], dtype=first[0].dtype)
+        sc2 = np.zeros((n,) + first[1].shape[1:], dtype=first[1].dtype)
+        pos3 = np.zeros((n,) + first[2].shape[1:], dtype=first[2].dtype)
+        sc3 = np.zeros((n,) + first[3].shape[1:], dtype=first[3].dtype)
+        t2 = t3 = 0.0
+        for r, g in enumerate(gathered):
+            if not g:
+                continue
+            rows = list(range(r, n, R))
+            pos2[rows], sc2[rows], pos3[rows], sc3[rows] = g[0], g[1], g[2], g[3]
+            t2, t3 = max(t2, g[4] or 0.0), max(t3, g[5] or 0.0)
+        ids1_dev, sc1 = got
+        ids1_h = ids1_dev.cpu().numpy()
+        sc1_h = sc1.cpu().numpy() if hasattr(sc1, "cpu") else sc1
+        total = (time.time() - total_start) / n if total_start is not None else None
+        timing = self.config.enable_timing
+        return self._records_from_arrays(queries, top_k, ids1_h, sc1_h, pos2, sc2, pos3, sc3, t1,
+                                         t2 / n if timing else None, t3 / n if timing else None, total)

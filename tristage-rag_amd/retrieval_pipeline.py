@@ -297,47 +297,73 @@ class RetrievalPipeline:
         ``save_intermediate_results``, else the final top_k per query).  Same records as the per-record path
         (tests).  None when a precondition is missing (HIP index on the device path, complete token store,
         complete stage-3 id cache, at least stage1_top_k documents) — the caller then takes the record path."""
-        import torch
-        s1, s2, s3 = self.stage1, self.stage2, self.stage3
-        if not (getattr(s2, "token_store", None) is not None and len(s2.token_store)
-                and getattr(s3, "_pairs_usable", False) and hasattr(s1, "search_many_arrays")):
+        if not self._arrays_ready():
             return None
-        timing = self.config.enable_timing
         n = len(queries)
-
-        def tick():
-            if timing:
-                if torch.cuda.is_available():
-                    torch.cuda.synchronize()
-                return time.time()
+        total_start = t = self._tick()
+        got = self._arrays_stage1(queries)
+        if got is None:
             return None
-        total_start = t = tick()
-        got = s1.search_many_arrays(queries, self.config.stage1_top_k)
+        ids1_dev, sc1 = got
+        t1 = (self._tick() - t) / n if t is not None else None
+        later = self._arrays_stage23(queries, ids1_dev)
+        if later is None:
+            return None
+        pos2_h, sc2_h, pos3_h, sc3_h, t2s, t3s = later
+        t2 = t2s / n if t2s is not None else None
+        t3 = t3s / n if t3s is not None else None
+        ids1_h = ids1_dev.cpu().numpy()
+        sc1_h = sc1.cpu().numpy() if hasattr(sc1, "cpu") else sc1
+        total = (time.time() - total_start) / n if total_start is not None else None
+        return self._records_from_arrays(queries, top_k, ids1_h, sc1_h, pos2_h, sc2_h, pos3_h, sc3_h, t1, t2, t3, total)
+
+    def _tick(self) -> Optional[float]:
+        if not self.config.enable_timing:
+            return None
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return time.time()
+
+    def _arrays_ready(self) -> bool:
+        s1, s2, s3 = self.stage1, self.stage2, self.stage3
+        return bool(getattr(s2, "token_store", None) is not None and len(s2.token_store)
+                    and getattr(s3, "_pairs_usable", False) and hasattr(s1, "search_many_arrays"))
+
+    def _arrays_stage1(self, queries: List[str]):
+        """-> (ids int64 [B, k] on the token store's device, scores [B, k] tensor or numpy) or None."""
+        import torch
+        got = self.stage1.search_many_arrays(queries, self.config.stage1_top_k)
         if got is None:
             return None
         ids1, sc1 = got
-        dev = s2.token_store.data.device
-        ids1_dev = ids1 if torch.is_tensor(ids1) else torch.from_numpy(ids1).to(dev)
-        t1 = (tick() - t) / n if timing else None
-        t = tick() if timing else None
-        r2 = s2.rescore_arrays(queries, ids1_dev)
+        dev = self.stage2.token_store.data.device
+        ids1_dev = ids1.to(dev) if torch.is_tensor(ids1) else torch.from_numpy(ids1).to(dev)
+        return ids1_dev, sc1
+
+    def _arrays_stage23(self, queries: List[str], ids1_dev):
+        """Stages 2 and 3 of `queries` (row i of ids1_dev = the stage-1 ids of queries[i]) ->
+        (pos2, sc2, pos3, sc3 as host arrays, stage-2 seconds, stage-3 seconds) or None."""
+        import torch
+        t = self._tick()
+        r2 = self.stage2.rescore_arrays(queries, ids1_dev)
         if r2 is None:
             return None
         pos2, sc2 = r2
-        ids2_dev = torch.gather(ids1_dev, 1, pos2)
-        t2 = (tick() - t) / n if timing else None
-        t = tick() if timing else None
-        r3 = s3.rerank_arrays(queries, ids2_dev)
+        ids2_dev = torch.gather(ids1_dev.to(pos2.device), 1, pos2)
+        t2 = (self._tick() - t) if t is not None else None
+        t = self._tick()
+        r3 = self.stage3.rerank_arrays(queries, ids2_dev)
         if r3 is None:
             return None
         pos3, sc3 = r3
-        # one trip to the host for everything the records need
-        ids1_h = ids1_dev.cpu().numpy()
-        sc1_h = sc1.cpu().numpy() if torch.is_tensor(sc1) else sc1
-        pos2_h, sc2_h = pos2.cpu().numpy(), sc2.cpu().numpy()
-        pos3_h, sc3_h = pos3.cpu().numpy(), sc3.cpu().numpy()
-        t3 = (tick() - t) / n if timing else None
-        total = (time.time() - total_start) / n if timing else None
+        out = (pos2.cpu().numpy(), sc2.cpu().numpy(), pos3.cpu().numpy(), sc3.cpu().numpy())
+        t3 = (self._tick() - t) if t is not None else None
+        return out + (t2, t3)
+
+    def _records_from_arrays(self, queries, top_k, ids1_h, sc1_h, pos2_h, sc2_h, pos3_h, sc3_h, t1, t2, t3, total):
+        s1 = self.stage1
+        n = len(queries)
         docs, meta = s1.documents, s1.doc_metadata
         keep = self.config.save_intermediate_results
 
@@ -364,8 +390,7 @@ class RetrievalPipeline:
         if not keep:   # _assemble_many only tests the lists of a non-empty stage for truth
             out1 = [[True]] * n
             out2 = [[True]] * n
-        res = self._assemble_many(queries, top_k, out1, out2, out3, t1, t2, t3, total)
-        return res
+        return self._assemble_many(queries, top_k, out1, out2, out3, t1, t2, t3, total)
 
     def _later_stages_many(self, queries, s1):
         """Stages 2 and 3 for several queries -> (stage-2 lists, stage-3 lists, per-query time shares)."""
