@@ -549,3 +549,33 @@ def test_one_launch_scan_falls_back_exactly_on_massive_ties(torch_mod):
     Dc, Ic = idx.search(q2, k, classic=True)
     assert torch.equal(I2, Ic) and torch.equal(D2, Dc)
     idx.close()
+
+
+@pytest.mark.parametrize("n,d,k,B,qdt", [(5000, 768, 100, 33, "f32"), (70_001, 600, 50, 70, "f32"), (200_000, 768, 1000, 64, "f32"),
+                                          (33, 520, 7, 1, "f32"), (150_000, 704, 10, 5, "f16")])
+def test_fp32_storage_split_scan_matches_oracle(torch_mod, n, d, k, B, qdt):
+    """TS_F32 storage with 512 < d <= 768 runs the bf16x3 split scan (ts_scan_f32s.hip: every fp32 value as three
+    bf16 terms, six 16-bit MFMAs per k step) instead of the exact-f32 MFMA: dense path, filter path (>= 32768 rows),
+    more than 32 queries (two passes), reconstruct and ts_index_scores on the same layout — against the float64
+    oracle with the same near-tie rule as every other stage-1 test (the dropped terms are < 2e-7 for unit rows)."""
+    torch = torch_mod
+    corpus = make_corpus(n, d, seed=1234, dtype="f32")
+    if n > 100:
+        corpus[n // 2: n // 2 + 20] = corpus[3]                   # exact ties
+    queries = make_corpus(B, d, seed=4321, dtype="f32")
+    idx = _index(d, "f32", torch.from_numpy(corpus).cuda())
+    assert np.array_equal(idx.reconstruct_n(0, n), corpus)      # fp32 storage keeps all 32 bits
+    q = torch.from_numpy(queries).cuda()
+    if qdt == "f16":
+        queries = oracle.quantize(queries, "f16")
+        q = torch.from_numpy(queries).cuda().half()
+    D, I = idx.search(q, k)
+    check_topk(D.cpu().numpy(), I.cpu().numpy(), corpus, queries, k)
+    if n >= 32768:
+        assert idx.last_search_info()["path"] == "filter" and not idx.last_search_info()["one_launch"]
+        D2, I2 = idx.search(q, k, exact_dense=True)
+        assert torch.equal(I, I2) and torch.equal(D, D2)
+    S = idx.scores(q[: min(B, 3)])
+    for b in range(min(B, 3)):
+        np.testing.assert_allclose(S[b].cpu().numpy(), oracle.scores_f64(corpus, queries[b]), atol=3e-6)
+    idx.close()

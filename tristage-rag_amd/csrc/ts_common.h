@@ -141,6 +141,12 @@ int ts_launch_scan(const TsLayout& L, int mode, int qh, const ScanParams& p,
                    int num_cus, hipStream_t stream);
 // LDS bytes the scan kernel needs for qh*32 queries (Q image + candidate staging)
 size_t ts_scan_lds_bytes(const TsLayout& L, int qh);
+// fp32 storage, 32-query passes, 512 < d <= 768: the bf16x3 split scan (ts_scan_f32s.hip) instead of the exact-f32 MFMA
+bool ts_use_f32_split(const TsLayout& L, int qh);
+size_t ts_scan_f32s_lds_bytes(const TsLayout& L);
+int ts_launch_scan_f32s(const TsLayout& L, int mode, const ScanParams& p, int num_cus, hipStream_t stream);
+int ts_launch_qprep_f32s(const TsLayout& L, const void* q, int q_dtype, int nq, uint4* qimg, uint32_t* cand_cnt,
+                         uint32_t* status, hipStream_t stream);
 
 // rows [n, dim] (row-major, in_dtype) -> tiled storage at rows [row0, row0+n)
 int ts_launch_relayout(const TsLayout& L, const void* rows, int in_dtype,

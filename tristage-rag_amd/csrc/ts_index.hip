@@ -617,7 +617,8 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   // roofline object; pipelined (TS_FLAG_PIPELINE) the five-launch path already hides its preparation under the
   // previous scan and is 3 % ahead (0.335 vs 0.345 ms with the exchange).  TS_FLAG_ONE_LAUNCH forces it anywhere.
   const bool want_fused = (flags & TS_FLAG_ONE_LAUNCH) || (!pipe && N <= kOneLaunchMaxRows);
-  const bool fused = filter && !(flags & TS_FLAG_CLASSIC) && want_fused && plan_fused(h, N, nblk, k, pipe, &fp);
+  const bool fused = filter && !(flags & TS_FLAG_CLASSIC) && want_fused && !ts_use_f32_split(h->L, qh) &&
+                     plan_fused(h, N, nblk, k, pipe, &fp);   // (fp32 storage at 32 queries per pass: the split scan, five launches)
   // (the one-launch search has no preparation phase: what remains of "P" rides on the scan stream)
   hipStream_t sP = pipe ? (fused ? h->s_scan : h->s_pro) : s, sS = pipe ? h->s_scan : s, sL = pipe ? h->s_sel : s;
   // the set may still be in use on the GPU by the (asynchronous) search that had it last, possibly

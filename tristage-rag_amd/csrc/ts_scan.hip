@@ -21,6 +21,7 @@
 //     query out of millions) are appended to per-query candidate lists, so the
 //     B x N score matrix is never materialised.
 #include "ts_scan_dev.h"
+#include <stdlib.h>
 
 // One persistent wave streams row blocks gw, gw+W, gw+2W, ... (W = waves in
 // the grid).  No barrier after the prologue.
@@ -146,7 +147,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
   if constexpr (MODE == SCAN_FILTER) flush_stage(p, st, tid);
 }
 
+bool ts_use_f32_split(const TsLayout& L, int qh) {
+  if (L.dtype != TS_F32 || qh != 1) return false;
+#ifdef TS_TUNING   // A/B: TS_NO_F32_SPLIT=1 keeps the exact-f32 MFMA kernel
+  static const bool off = getenv("TS_NO_F32_SPLIT") != nullptr;
+  if (off) return false;
+#endif
+  const size_t s = ts_scan_f32s_lds_bytes(L);
+  if (s == 0 || s > 160 * 1024) return false;
+  // only where the exact-f32 kernel could not take 64 queries per pass anyway
+  return (size_t)L.kg * 2 * 1024 + sizeof(StageLds) > 160 * 1024;
+}
+
 size_t ts_scan_lds_bytes(const TsLayout& L, int qh) {
+  if (ts_use_f32_split(L, qh)) return ts_scan_f32s_lds_bytes(L);
   return (size_t)L.kg * qh * 1024 + sizeof(StageLds);
 }
 
@@ -185,6 +199,7 @@ static int launch_scan_dt(const TsLayout& L, int mode, int qh,
 int ts_launch_scan(const TsLayout& L, int mode, int qh, const ScanParams& p,
                    int num_cus, hipStream_t stream) {
   if (p.nwork <= 0) return TS_OK;
+  if (ts_use_f32_split(L, qh)) return ts_launch_scan_f32s(L, mode, p, num_cus, stream);
   if (ts_scan_lds_bytes(L, qh) > 160 * 1024) {
     ts_set_error("dimension %d too large for the LDS-resident query image", L.dim);
     return TS_ERR_UNSUPPORTED;
@@ -396,6 +411,7 @@ __global__ void qprep_kernel(const TIN* q, int nq, int dim, int kg, int qh, int 
 int ts_launch_qprep(const TsLayout& L, const void* q, int q_dtype, int nq, int qh,
                     uint4* qimg, uint32_t* cand_cnt, uint32_t* status,
                     hipStream_t stream) {
+  if (ts_use_f32_split(L, qh)) return ts_launch_qprep_f32s(L, q, q_dtype, nq, qimg, cand_cnt, status, stream);
   const int units = L.kg * qh * 64;
   const int blocks = (units + 255) / 256;
   switch (q_dtype) {

@@ -94,7 +94,9 @@ __device__ __forceinline__ void epilogue_dense(const ScanParams& p,
 // 27 % of the kernel at 10M x 768: each append stalls its wave for microseconds
 // behind the HBM stream — measured, DESIGN.md "candidate staging".)
 #define STAGE_CAP 2048
-struct StageLds {
+template <int CAP>
+struct StageLdsT {
+  static constexpr uint32_t kCap = CAP;
   uint32_t cnt;
   uint32_t tau_flag;        // ts_fused.hip: wave 0 has published this launch's thresholds in tauv[]
   uint32_t arrived;         // ts_fused.hip: waves of this workgroup that have delivered their sample
@@ -103,13 +105,14 @@ struct StageLds {
   uint32_t qcnt[TS_MAX_Q];
   uint32_t qbase[TS_MAX_Q];
   uint32_t qoff[TS_MAX_Q];
-  float score[STAGE_CAP];
-  int32_t id[STAGE_CAP];
-  uint8_t q[STAGE_CAP];
+  float score[CAP];
+  int32_t id[CAP];
+  uint8_t q[CAP];
 };
+typedef StageLdsT<STAGE_CAP> StageLds;
 
-template <int QH>
-__device__ __forceinline__ void epilogue_filter(const ScanParams& p, StageLds* st,
+template <int QH, class SL>
+__device__ __forceinline__ void epilogue_filter(const ScanParams& p, SL* st,
                                                 const f32x16 (&acc)[QH],
                                                 const float (&tau)[QH],
                                                 int64_t blk, int lane) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ void epilogue_filter(const ScanParams& p, StageLds* s
       for (int r = 0; r < 16; ++r) {
         if (mask & (1u << r)) {
           const int32_t id = (int32_t)(row_base + acc_row(r, lane));
-          if (slot < STAGE_CAP) {
+          if (slot < SL::kCap) {
             st->score[slot] = acc[hq][r];
             st->id[slot] = id;
             st->q[slot] = (uint8_t)q;
@@ -156,9 +159,10 @@ __device__ __forceinline__ void epilogue_filter(const ScanParams& p, StageLds* s
 
 // Workgroup-wide: move the staged survivors to the per-query lists.  One global
 // atomic per (workgroup, query) reserves the slots.
-__device__ __forceinline__ void flush_stage(const ScanParams& p, StageLds* st, int tid) {
+template <class SL>
+__device__ __forceinline__ void flush_stage(const ScanParams& p, SL* st, int tid) {
   __syncthreads();
-  const uint32_t n = st->cnt < STAGE_CAP ? st->cnt : STAGE_CAP;
+  const uint32_t n = st->cnt < SL::kCap ? st->cnt : SL::kCap;
   if (n == 0) return;  // uniform: cnt is final after the barrier
   if (tid < TS_MAX_Q) { st->qcnt[tid] = 0; st->qoff[tid] = 0; }
   __syncthreads();
@@ -224,6 +228,9 @@ __device__ __forceinline__ uint16_t f32_to_storage16(float f, int dt) {
 
 // k index of element e (0..epl-1) of lane half h in group g
 __device__ __forceinline__ int frag_k(int dt, int g, int h, int e) {
-  return (dt == TS_F32) ? (8 * g + 2 * e + h) : (16 * g + 8 * h + e);
+  // f32: two consecutive units (g even, g odd) hold 8 consecutive k of a lane's row — k = 16(g/2) + 8h + 4(g&1) + e —
+  // so that a pair of units is the A operand of one 16-wide k step of the bf16x3 split scan (ts_scan_f32s.hip);
+  // the exact-f32 MFMA path does not care about the order (the query image uses the same map)
+  return (dt == TS_F32) ? (16 * (g >> 1) + 8 * h + 4 * (g & 1) + e) : (16 * g + 8 * h + e);
 }
 
