@@ -7,11 +7,13 @@
 //       x = hi + mid + lo          hi = trunc16(x), mid = trunc16(x - hi), lo = trunc16(x - hi - mid)
 // (8 + 8 + 8 significand bits: EXACT for normal numbers, the subtractions are exact in fp32), the query image
 // holds the same three terms of every query, and a k step of 16 is six v_mfma_f32_32x32x16_bf16
-//       al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh
+//       ah*bh + ah*bm + am*bh   (one accumulator)      al*bh + ah*bl + am*bm   (a second one, added at the end)
 // (products of bf16 values are exact; fp32 accumulation).  The three dropped terms (am*bl, al*bm, al*bl) are
 // below 2^-24 |a||b| each: for unit-norm rows the score error they add is < 2e-7, inside the float64 near-tie
 // rule of the parity tests (2e-6).  Matrix work per k step: 6 x 32 cycles instead of 8 x 64; the split costs
-// ~52 VALU instructions per k step, which overlap with the MFMAs.
+// ~44 VALU instructions per k step (and / sub / and / sub per value, v_perm_b32 to pack two upper halves).
+// Measured at 10 M x 768 (32 queries per pass): 5.59 ms per pass with the exact-f32 MFMA (5.5 TB/s = 69 %),
+// 4.99 ms with one accumulator chain and shift+or packing (6.15 TB/s), 4.59 ms as it stands (6.69 TB/s = 84 %).
 //
 // Scope: 32 queries per pass (three 16-bit query images of 32 queries are 144 KiB at d = 768) and only where the
 // exact-f32 path could not take 64 queries per pass anyway (512 < d <= 768 — which includes the headline
@@ -34,14 +36,14 @@ __device__ __forceinline__ void f32s_split8(const u32x4& a0, const u32x4& a1, u3
     h[j] = f32s_trunc(x);
     const float r1 = x - __builtin_bit_cast(float, h[j]);
     m[j] = f32s_trunc(r1);
-    const float r2 = r1 - __builtin_bit_cast(float, m[j]);
-    l[j] = f32s_trunc(r2);
+    l[j] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[j]));   // (its upper half is taken below)
   }
+  // two upper halves -> one dword of two bf16 (v_perm_b32: bytes 2,3 of the even element, bytes 2,3 of the odd one)
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    hi[d] = (h[2 * d] >> 16) | h[2 * d + 1];
-    mid[d] = (m[2 * d] >> 16) | m[2 * d + 1];
-    lo[d] = (l[2 * d] >> 16) | l[2 * d + 1];
+    hi[d] = __builtin_amdgcn_perm(h[2 * d + 1], h[2 * d], 0x07060302u);
+    mid[d] = __builtin_amdgcn_perm(m[2 * d + 1], m[2 * d], 0x07060302u);
+    lo[d] = __builtin_amdgcn_perm(l[2 * d + 1], l[2 * d], 0x07060302u);
   }
 }
 
@@ -49,17 +51,20 @@ __device__ __forceinline__ void f32s_mma(f32x16& acc, const u32x4& a, const u32x
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
 }
 
-// one k step of 16: ring units (a0, a1) of this lane's row against query-image group G (three terms)
-__device__ __forceinline__ void f32s_step(f32x16& acc, const u32x4& a0, const u32x4& a1, const u32x4* ql, int G) {
+// one k step of 16: ring units (a0, a1) of this lane's row against query-image group G (three terms).  Two
+// accumulators — the small cross terms and the large ones — so that consecutive MFMAs are not one dependency
+// chain (a wave issues in order: six dependent 32-cycle MFMAs stall it for ~190 cycles per k step).
+__device__ __forceinline__ void f32s_step(f32x16& acc, f32x16& acc_small, const u32x4& a0, const u32x4& a1,
+                                          const u32x4* ql, int G) {
   u32x4 ah, am, al;
   f32s_split8(a0, a1, ah, am, al);
   const u32x4 bh = ql[(size_t)(G * 3 + 0) * 64], bm = ql[(size_t)(G * 3 + 1) * 64], bl = ql[(size_t)(G * 3 + 2) * 64];
-  f32s_mma(acc, al, bh);   // small terms first
-  f32s_mma(acc, ah, bl);
-  f32s_mma(acc, am, bm);
-  f32s_mma(acc, am, bh);
-  f32s_mma(acc, ah, bm);
   f32s_mma(acc, ah, bh);
+  f32s_mma(acc_small, al, bh);
+  f32s_mma(acc, ah, bm);
+  f32s_mma(acc_small, ah, bl);
+  f32s_mma(acc, am, bh);
+  f32s_mma(acc_small, am, bm);
 }
 
 template <int MODE>
@@ -117,14 +122,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_f32s_kernel(ScanParams p) {
       const bool has_next = wn < p.nwork;
       const int64_t blkn = has_next ? (p.blk0 + wn * p.blk_stride) : blk;
       const u32x4* nxt = base + (size_t)blkn * blk_units;
-      f32x16 acc[1];
+      f32x16 acc[1], acc_small;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc_small[r] = 0.f; }
       int g0 = 0;
       for (; g0 < kg - TS_RING; g0 += TS_RING) {
 #pragma unroll
         for (int i = 0; i < TS_RING; i += 2) {
-          f32s_step(acc[0], ring[i], ring[i + 1], ql, (g0 + i) >> 1);
+          f32s_step(acc[0], acc_small, ring[i], ring[i + 1], ql, (g0 + i) >> 1);
           ring[i] = stream_load(cur + (size_t)(g0 + i + TS_RING) * 64);
           ring[i + 1] = stream_load(cur + (size_t)(g0 + i + 1 + TS_RING) * 64);
           __builtin_amdgcn_sched_barrier(0);
@@ -132,11 +137,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_f32s_kernel(ScanParams p) {
       }
 #pragma unroll
       for (int i = 0; i < TS_RING; i += 2) {   // tail: the ring is refilled from the wave's next row block
-        f32s_step(acc[0], ring[i], ring[i + 1], ql, (g0 + i) >> 1);
+        f32s_step(acc[0], acc_small, ring[i], ring[i + 1], ql, (g0 + i) >> 1);
         ring[i] = stream_load(nxt + (size_t)i * 64);
         ring[i + 1] = stream_load(nxt + (size_t)(i + 1) * 64);
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += acc_small[r];
       if constexpr (MODE == SCAN_DENSE)
         epilogue_dense<1>(p, acc, w, blk, lane);
       else
