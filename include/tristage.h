@@ -229,6 +229,19 @@ int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, const int64
 int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
                    double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream);
 
+/* ---- fused residual add + LayerNorm (between the GEMMs of the encoder forwards) ---
+ * The cross-encoder forward the reference reaches through CrossEncoder.predict
+ * (src/stage3_reranker.py:127-131) is PyTorch-ROCm GEMMs and attention here too; the
+ * residual add, LayerNorm and the cast for the next GEMM between them are one pass:
+ *   y = LayerNorm(x + residual) * gamma + beta  over the last dimension H (fp32
+ *   statistics and arithmetic, like torch.layer_norm);
+ * x [rows, H] of x_dtype; residual fp32 [rows, H] or NULL; gamma / beta fp32 [H];
+ * y is written as fp32 (out_f32, may be NULL) and / or in lp_dtype (out_lp, TS_F16 or
+ * TS_BF16, may be NULL).  H a multiple of 4, <= 2048; pointers 16-byte aligned (device). */
+int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
+                     const float* beta, float eps, int64_t rows, int32_t H, float* out_f32,
+                     void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
+
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */
 int ts_maxsim_release_scratch(int32_t device);

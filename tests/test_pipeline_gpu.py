@@ -231,3 +231,32 @@ def test_array_path_search_many_on_gpu(tmp_path):
     assert float((lean - ref).abs().max()) < 4e-3            # bf16 GEMMs of different shapes (fused QKV)
     text = ce.logits([[queries[int(a)], docs[int(b)]] for a, b in zip(pq.tolist(), pd.tolist())], batch_size=300)
     assert float((text - ref).abs().max()) < 4e-3            # assembled ids == tokenised text pairs
+
+
+@pytest.mark.parametrize("xdt,H,rows", [("bf16", 384, 5000), ("f16", 1024, 777), ("f32", 64, 33), ("bf16", 2048, 65), ("bf16", 772, 100)])
+def test_fused_add_layernorm_matches_torch(xdt, H, rows):
+    """ts_add_layernorm (residual add + LayerNorm + cast in one pass) against torch: (x + residual) in fp32,
+    torch.layer_norm in fp32, .to(16-bit) — fp32 output to 2e-6, the 16-bit output equal up to one rounding step."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import add_layernorm
+    g = torch.Generator(device="cuda").manual_seed(H + rows)
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[xdt]
+    x = (torch.randn((rows, H), generator=g, device="cuda") * 0.7).to(tdt)
+    res = torch.randn((rows, H), generator=g, device="cuda") * 2.0 + 0.3
+    gamma = torch.rand((H,), generator=g, device="cuda") + 0.5
+    beta = torch.randn((H,), generator=g, device="cuda") * 0.1
+    for lp in (torch.bfloat16, torch.float16):
+        for r in (res, None):
+            want = F.layer_norm(x.float() + r if r is not None else x.float(), (H,), gamma, beta, 1e-12)
+            y32, ylp = add_layernorm(x, r, gamma, beta, 1e-12, lp_dtype=lp)
+            assert y32.dtype == torch.float32 and ylp.dtype == lp
+            assert float((y32 - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+            step = 2.0 ** (-8 if lp == torch.bfloat16 else -11)
+            assert float((ylp.float() - want).abs().max()) <= step * float(want.abs().max()) + 1e-6
+            assert torch.equal(ylp, y32.to(lp))                   # the 16-bit copy is the rounded fp32 result
+    only32, none_lp = add_layernorm(x, res, gamma, beta, 1e-5, lp_dtype=None)
+    assert none_lp is None and only32 is not None
+    # 3-D input, as the encoder passes it
+    y32, ylp = add_layernorm(x.view(1, rows, H), res.view(1, rows, H), gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
+    assert y32.shape == (1, rows, H)

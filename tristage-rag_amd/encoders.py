@@ -703,6 +703,7 @@ class LeanBertClassifier:
         base = hf_model.bert if self.kind == "bert" else hf_model.roberta
         self.cd = compute_dtype
         cd = compute_dtype or torch.float32
+        self.fused_layernorm = True   # 16-bit compute on a GPU: residual add + LayerNorm + cast as one HIP pass (ts_add_layernorm)
         emb = base.embeddings
         self.word, self.pos, self.typ = emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight
         self.emb_ln = (emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
@@ -738,21 +739,31 @@ class LeanBertClassifier:
             nonpad = (input_ids != self.pad_idx).to(torch.int64)
             pos = torch.cumsum(nonpad, dim=1) * nonpad + self.pad_idx
         x = self.word[input_ids] + self.typ[token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids)]
-        x = x + self.pos[pos]
-        x = F.layer_norm(x.float(), (x.shape[-1],), self.emb_ln[0], self.emb_ln[1], self.emb_ln[2])
+        x = (x + self.pos[pos]).float()
         H, nh = x.shape[-1], self.heads
+        fused = (self.fused_layernorm and self.cd in (torch.bfloat16, torch.float16) and x.is_cuda and H % 4 == 0 and H <= 2048)
+        if fused:
+            from .index import add_layernorm   # HIP kernel (raises without the library)
+
+            def add_ln(new, old, ln):          # -> (fp32 stream, 16-bit copy for the next GEMM) in one pass
+                return add_layernorm(new, old, ln[0], ln[1], ln[2], lp_dtype=cd)
+        else:
+            def add_ln(new, old, ln):          # the same arithmetic in torch ops (16-bit + fp32 -> fp32 add, fp32 LayerNorm, cast)
+                y = F.layer_norm(new + old if old is not None else new, (H,), ln[0], ln[1], ln[2])
+                return y, y.to(cd)
+        x, xb = add_ln(x, None, self.emb_ln)
         mask = None
         if attention_mask is not None and not bool(attention_mask.all()):
             mask = attention_mask.to(torch.bool)[:, None, None, :]
         for p in self.layers:
-            qkv = F.linear(x.to(cd), p["wqkv"], p["bqkv"]).view(B, L, 3, nh, H // nh)
+            qkv = F.linear(xb, p["wqkv"], p["bqkv"]).view(B, L, 3, nh, H // nh)
             q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B, heads, L, dh] views
             a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
             o = F.linear(a.transpose(1, 2).reshape(B, L, H), p["wo"], p["bo"])
-            x = F.layer_norm(o + x, (H,), p["ln1"][0], p["ln1"][1], p["ln1"][2])   # (bf16 + fp32 -> fp32)
-            f = F.linear(self.act(F.linear(x.to(cd), p["w1"], p["b1"])), p["w2"], p["b2"])
-            x = F.layer_norm(f + x, (H,), p["ln2"][0], p["ln2"][1], p["ln2"][2])
-        y = x[:, 0].to(cd)
+            x, xb = add_ln(o, x, p["ln1"])
+            f = F.linear(self.act(F.linear(xb, p["w1"], p["b1"])), p["w2"], p["b2"])
+            x, xb = add_ln(f, x, p["ln2"])
+        y = xb[:, 0]
         for w, b, tanh in self.head:
             y = F.linear(y, w, b)
             if tanh:

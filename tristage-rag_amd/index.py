@@ -427,3 +427,30 @@ def maxsim_indexed_batch(q_packed, q_offsets, store, starts, lens, cand_offsets,
                                            q_packed.shape[1], _tensor_dtype(q_packed), 0 if mode == "maxsim" else 1,
                                            ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out
+
+
+def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32: bool = True):
+    """``LayerNorm(x + residual) * gamma + beta`` over the last dimension in ONE pass on the GPU (ts_add_layernorm):
+    x [..., H] (fp32 / fp16 / bf16), residual fp32 of the same shape or None, gamma / beta fp32 [H].
+    Returns (y as fp32 or None, y in ``lp_dtype`` or None) — the next residual and the next GEMM's input."""
+    torch = _torch()
+    lib = _lib.load()
+    H = int(x.shape[-1])
+    x = x.contiguous()
+    rows = x.numel() // H
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.dtype != torch.float32 or residual.shape != x.shape:
+            raise ValueError("residual must be float32 with x's shape")
+    gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+    out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    outlp = torch.empty(x.shape, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
+    dev = x.device.index
+    _lib.check(lib.ts_add_layernorm(ctypes.c_void_p(x.data_ptr()), _tensor_dtype(x),
+                                    ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+                                    ctypes.c_void_p(gamma.data_ptr()), ctypes.c_void_p(beta.data_ptr()), float(eps), rows, H,
+                                    ctypes.c_void_p(out32.data_ptr()) if out32 is not None else None,
+                                    ctypes.c_void_p(outlp.data_ptr()) if outlp is not None else None,
+                                    _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev,
+                                    ctypes.c_void_p(_stream_ptr(dev))))
+    return out32, outlp
