@@ -34,6 +34,7 @@ def main():
                     help="stage-3 token ids cached at add time: search_many runs every stage on arrays (needs --store --many)")
     ap.add_argument("--s3-batch", type=int, default=1024, help="pairs per cross-encoder forward in search_many")
     ap.add_argument("--no-lean", action="store_true", help="stage 3 through the transformers module instead of the written-out forward")
+    ap.add_argument("--torch-attention", action="store_true", help="stage 3 attention through torch's masked SDPA instead of ts_attention_varlen")
     ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
@@ -59,6 +60,8 @@ def main():
     p.initialize_stages()
     if args.no_lean and hasattr(p.stage3.model, "lean_forward"):
         p.stage3.model.lean_forward = False
+    if args.torch_attention and hasattr(p.stage3.model, "_lean_model") and p.stage3.model._lean_model():
+        p.stage3.model._lean_model().fused_attention = False
     t0 = time.perf_counter()
     p.add_documents(docs)
     torch.cuda.synchronize()

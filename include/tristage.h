@@ -242,6 +242,22 @@ int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, cons
                      const float* beta, float eps, int64_t rows, int32_t H, float* out_f32,
                      void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
 
+/* ---- self-attention of a right-padded batch (the attention of those forwards) -----
+ * softmax(Q K^T * scale) V per head over the first lens[b] tokens of sequence b only —
+ * what torch's scaled_dot_product_attention computes under the padding mask of
+ * CrossEncoder.predict's tokenizer batch (src/stage3_reranker.py:127-131), without
+ * a mask tensor and without work on the padding.  qkv [B, L, 3, heads, dh] of dtype
+ * (TS_F16 / TS_BF16): the output of the fused Q/K/V projection, read in place;
+ * lens int32 [B] (device; clamped to L; 0 = nothing written for that sequence);
+ * out [B, L, heads*dh] of dtype — rows at padded positions are NOT written.  fp32
+ * softmax statistics and accumulation, probabilities rounded to dtype before the
+ * P V product (as flash attention does).  dh 32 or 64; (L rounded up to 32) * dh * 4
+ * + 16 dh bytes of LDS must fit 160 KB (L <= 1248 at dh 32, 608 at dh 64);
+ * pointers 16-byte aligned, B <= 65535.                                            */
+int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads,
+                        int32_t dh, int32_t dtype, float scale, void* out, int32_t device,
+                        void* stream);
+
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */
 int ts_maxsim_release_scratch(int32_t device);

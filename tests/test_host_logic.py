@@ -539,12 +539,15 @@ def test_pair_assembler_reproduces_the_tokenizer(tmp_path, kind, max_length):
     want = tok([qs[i] for i in pq.tolist()], [docs[i] for i in pd.tolist()], truncation=True, padding=True,
                max_length=max_length, return_tensors="pt")
     for k in got:
-        assert torch.equal(got[k], want[k]), k
+        if k != "lengths":
+            assert torch.equal(got[k], want[k]), k
+    assert got["lengths"].dtype == torch.int32 and torch.equal(got["lengths"].long(), want["attention_mask"].sum(1))
     assert int(plan["total"].max()) <= max_length
     sel = torch.tensor([5, 17, 3])                                 # a sub-batch, padded to a given width
     sub = pa.batch(plan, sel, width=int(plan["total"][sel].max()) + 2)
     assert sub["input_ids"].shape[1] == int(plan["total"][sel].max()) + 2
     assert torch.equal(sub["attention_mask"].sum(1), plan["total"][sel])
+    assert torch.equal(sub["lengths"].long(), plan["total"][sel])
 
 
 def test_pair_assembler_refuses_a_tokenizer_it_cannot_restate():

@@ -231,6 +231,20 @@ def test_array_path_search_many_on_gpu(tmp_path):
     assert float((lean - ref).abs().max()) < 4e-3            # bf16 GEMMs of different shapes (fused QKV)
     text = ce.logits([[queries[int(a)], docs[int(b)]] for a, b in zip(pq.tolist(), pd.tolist())], batch_size=300)
     assert float((text - ref).abs().max()) < 4e-3            # assembled ids == tokenised text pairs
+    # the attention kernel's three entries: promised lengths, a prefix mask it verifies itself, and a mask with a hole
+    # (not a right-padded batch: torch's masked kernel takes over) — each against the transformers module
+    ce.lean_forward = True
+    no_len = {k: v for k, v in enc.items() if k != "lengths"}
+    assert float((ce.logits_from_ids(no_len) - ref).abs().max()) < 4e-3
+    ce._lean.fused_attention = False
+    assert float((ce.logits_from_ids(no_len) - ref).abs().max()) < 4e-3
+    ce._lean.fused_attention = True
+    holed = {k: v.clone() for k, v in no_len.items()}
+    holed["attention_mask"][:, 3] = 0
+    ce.lean_forward = False
+    ref_h = ce.logits_from_ids(holed)
+    ce.lean_forward = True
+    assert float((ce.logits_from_ids(holed) - ref_h).abs().max()) < 4e-3
 
 
 @pytest.mark.parametrize("xdt,H,rows", [("bf16", 384, 5000), ("f16", 1024, 777), ("f32", 64, 33), ("bf16", 2048, 65), ("bf16", 772, 100)])
@@ -260,3 +274,56 @@ def test_fused_add_layernorm_matches_torch(xdt, H, rows):
     # 3-D input, as the encoder passes it
     y32, ylp = add_layernorm(x.view(1, rows, H), res.view(1, rows, H), gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
     assert y32.shape == (1, rows, H)
+
+
+@pytest.mark.parametrize("dt,B,L,nh,dh", [("bf16", 37, 168, 12, 32), ("f16", 9, 256, 6, 64), ("bf16", 5, 33, 2, 32),
+                                          ("bf16", 3, 512, 4, 64), ("f16", 4, 1000, 2, 32)])
+def test_attention_varlen_matches_torch(dt, B, L, nh, dh):
+    """ts_attention_varlen against an fp32 softmax(QK^T/sqrt(dh))V over each sequence's valid tokens (float64-free
+    torch reference computed from the same 16-bit q, k, v), and against torch's masked SDPA in the same dtype.
+    Tolerance: probabilities and the output are rounded to the 16-bit type (2^-8 bf16 / 2^-11 fp16 relative steps) —
+    3 steps of the output scale."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import attention_varlen
+    g = torch.Generator(device="cuda").manual_seed(B * L + dh)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    H = nh * dh
+    qkv = (torch.randn((B, L, 3 * H), generator=g, device="cuda") * 1.5).to(tdt)
+    lens = torch.randint(1, L + 1, (B,), generator=g, device="cuda").to(torch.int32)
+    lens[0] = L
+    if B > 2:
+        lens[1], lens[2] = 1, 32
+    sentinel = 7.0
+    out = torch.full((B, L, H), sentinel, dtype=tdt, device="cuda")
+    got = attention_varlen(qkv, lens, nh, out=out)
+    assert got.data_ptr() == out.data_ptr()
+    q, k, v = (qkv.view(B, L, 3, nh, dh)[:, :, i].transpose(1, 2) for i in range(3))
+    valid = torch.arange(L, device="cuda")[None, :] < lens[:, None]
+    s = (q.float() @ k.float().transpose(-1, -2)) * dh ** -0.5
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, L, H)
+    step = 2.0 ** (-8 if dt == "bf16" else -11)
+    scale = float(want[valid].abs().max())
+    assert float((got.float() - want)[valid].abs().max()) <= 3 * step * scale
+    assert bool((got[~valid] == sentinel).all())                   # padded rows untouched
+    sd = F.scaled_dot_product_attention(q, k, v, attn_mask=valid[:, None, None, :]).transpose(1, 2).reshape(B, L, H)
+    assert float((got.float() - sd.float())[valid].abs().max()) <= 4 * step * scale
+    # default output buffer: zeros at the padding
+    z = attention_varlen(qkv, lens, nh)
+    assert torch.equal(z[valid], got[valid]) and bool((z[~valid] == 0).all())
+
+
+def test_attention_varlen_argument_errors():
+    import torch
+    from tristage_rag_amd.index import attention_varlen
+    from tristage_rag_amd import _lib
+    qkv = torch.zeros((2, 64, 3 * 2 * 16), dtype=torch.bfloat16, device="cuda")
+    lens = torch.full((2,), 64, dtype=torch.int32, device="cuda")
+    with pytest.raises(_lib.TriStageNativeError):
+        attention_varlen(qkv, lens, 2)                              # head dimension 16
+    with pytest.raises(ValueError):
+        attention_varlen(qkv, lens.long(), 2)
+    big = torch.zeros((1, 2048, 3 * 64), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_lib.TriStageNativeError):
+        attention_varlen(big, torch.full((1,), 2048, dtype=torch.int32, device="cuda"), 1)   # K and V^T do not fit LDS

@@ -675,7 +675,8 @@ class PairAssembler:
         ids = torch.where(t < a1, qpart, ids)
         ids = torch.where(t < a0, const(self.prefix, 0), ids)
         mask = (t < a4).to(torch.int64)
-        out = {"input_ids": ids, "attention_mask": mask}
+        # "lengths": the mask is a prefix mask by construction — the written-out forward needs no look at it (no host sync)
+        out = {"input_ids": ids, "attention_mask": mask, "lengths": a4.reshape(-1).clamp(max=L).to(torch.int32)}
         if self.has_types:
             out["token_type_ids"] = ((t >= a2) & (t < a4)).to(torch.int64) * self.type_b
         return out
@@ -704,6 +705,7 @@ class LeanBertClassifier:
         self.cd = compute_dtype
         cd = compute_dtype or torch.float32
         self.fused_layernorm = True   # 16-bit compute on a GPU: residual add + LayerNorm + cast as one HIP pass (ts_add_layernorm)
+        self.fused_attention = True   # ... and attention over each sequence's own tokens, no mask tensor (ts_attention_varlen)
         emb = base.embeddings
         self.word, self.pos, self.typ = emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight
         self.emb_ln = (emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps)
@@ -730,7 +732,9 @@ class LeanBertClassifier:
                          (c.out_proj.weight.detach().to(cd), c.out_proj.bias.detach().to(cd), False)]
 
     @torch.no_grad()
-    def __call__(self, input_ids, attention_mask, token_type_ids=None) -> torch.Tensor:
+    def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
+        """``lengths`` (int32 [B], optional): the caller's promise that attention_mask[b] is 1 exactly on the first
+        lengths[b] positions."""
         cd = self.cd or torch.float32
         B, L = input_ids.shape
         if self.kind == "bert":
@@ -752,14 +756,30 @@ class LeanBertClassifier:
                 y = F.layer_norm(new + old if old is not None else new, (H,), ln[0], ln[1], ln[2])
                 return y, y.to(cd)
         x, xb = add_ln(x, None, self.emb_ln)
-        mask = None
-        if attention_mask is not None and not bool(attention_mask.all()):
+        mask = lens = abuf = None
+        dh = H // nh
+        if (fused and self.fused_attention and dh in (32, 64) and B <= 65535 and (-(-L // 32) * 32 * 4 + 16) * dh <= 160 * 1024):
+            # right-padded batch (what tokenizers and PairAssembler produce): every sequence attends over its own tokens
+            lens = (lengths.to(torch.int32) if lengths is not None
+                    else torch.full((B,), L, dtype=torch.int32, device=x.device) if attention_mask is None
+                    else attention_mask.sum(1, dtype=torch.int32))
+            if lengths is None and attention_mask is not None and not bool(
+                    (attention_mask.to(torch.bool) == (torch.arange(L, device=x.device)[None, :] < lens[:, None])).all()):
+                lens = None                     # holes or left padding: the masked torch kernel below
+        if lens is not None:
+            from .index import attention_varlen
+            abuf = torch.zeros((B, L, H), dtype=cd, device=x.device)   # padded rows stay zero through all layers
+        elif attention_mask is not None and not bool(attention_mask.all()):
             mask = attention_mask.to(torch.bool)[:, None, None, :]
         for p in self.layers:
-            qkv = F.linear(xb, p["wqkv"], p["bqkv"]).view(B, L, 3, nh, H // nh)
-            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B, heads, L, dh] views
-            a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-            o = F.linear(a.transpose(1, 2).reshape(B, L, H), p["wo"], p["bo"])
+            qkv = F.linear(xb, p["wqkv"], p["bqkv"])
+            if lens is not None:
+                a = attention_varlen(qkv, lens, nh, out=abuf)
+            else:
+                qkv = qkv.view(B, L, 3, nh, dh)
+                q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B, heads, L, dh] views
+                a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, L, H)
+            o = F.linear(a, p["wo"], p["bo"])
             x, xb = add_ln(o, x, p["ln1"])
             f = F.linear(self.act(F.linear(xb, p["w1"], p["b1"])), p["w2"], p["b2"])
             x, xb = add_ln(f, x, p["ln2"])
@@ -855,6 +875,8 @@ class CrossEncoderModel:
             enc = {k: v for k, v in enc.items() if k != "token_type_ids"}
         lean = self._lean_model() if self.lean_forward else False
         if lean:
-            return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids")).reshape(enc["input_ids"].shape[0], -1)
+            return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"),
+                        lengths=enc.get("lengths")).reshape(enc["input_ids"].shape[0], -1)
+        enc = {k: v for k, v in enc.items() if k != "lengths"}
         with _autocast(self.device, self.use_amp, self.amp_dtype):
             return self.model(**enc).logits.float().reshape(enc["input_ids"].shape[0], -1)

@@ -454,3 +454,24 @@ def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32:
                                     _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev,
                                     ctypes.c_void_p(_stream_ptr(dev))))
     return out32, outlp
+
+
+def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None):
+    """Self-attention of a right-padded batch on the GPU (ts_attention_varlen): ``qkv`` [B, L, 3*heads*dh] (fp16 / bf16,
+    the fused projection's output, read in place), ``lens`` int32 [B] on the device.  Returns [B, L, heads*dh]; rows at
+    padded positions are zeros (``out`` given: left as they are)."""
+    torch = _torch()
+    lib = _lib.load()
+    B, L, W = (int(v) for v in qkv.shape)
+    if W % (3 * heads):
+        raise ValueError("last dimension must be 3 * heads * head_dim")
+    dh = W // (3 * heads)
+    if not qkv.is_contiguous() or lens.dtype != torch.int32 or lens.numel() != B or lens.device != qkv.device:
+        raise ValueError("qkv must be contiguous and lens int32 [B] on the same device")
+    if out is None:
+        out = torch.zeros((B, L, heads * dh), dtype=qkv.dtype, device=qkv.device)
+    dev = qkv.device.index
+    _lib.check(lib.ts_attention_varlen(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lens.data_ptr()), B, L, heads, dh,
+                                       _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5),
+                                       ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+    return out
