@@ -242,6 +242,16 @@ int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, cons
                      const float* beta, float eps, int64_t rows, int32_t H, float* out_f32,
                      void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
 
+/* The embedding layer of those models the same way: row r of the output is
+ *   LayerNorm((word[ids[r]] + type[type_ids[r]]) + position[pos_ids[r]]) * gamma + beta
+ * (the order of additions of BertEmbeddings / RobertaEmbeddings); ids / pos_ids /
+ * type_ids int64 [rows] on the device (type_ids NULL = type 0), tables fp32 [*, H]
+ * — indices are NOT range checked; outputs as for ts_add_layernorm.                */
+int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                       const float* word_tab, const float* pos_tab, const float* typ_tab,
+                       const float* gamma, const float* beta, float eps, int64_t rows, int32_t H,
+                       float* out_f32, void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
+
 /* ---- self-attention of a right-padded batch (the attention of those forwards) -----
  * softmax(Q K^T * scale) V per head over the first lens[b] tokens of sequence b only —
  * what torch's scaled_dot_product_attention computes under the padding mask of
@@ -251,8 +261,8 @@ int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, cons
  * lens int32 [B] (device; clamped to L; 0 = nothing written for that sequence);
  * out [B, L, heads*dh] of dtype — rows at padded positions are NOT written.  fp32
  * softmax statistics and accumulation, probabilities rounded to dtype before the
- * P V product (as flash attention does).  dh 32 or 64; (L rounded up to 32) * dh * 4
- * + 16 dh bytes of LDS must fit 160 KB (L <= 1248 at dh 32, 608 at dh 64);
+ * P V product (as flash attention does).  dh 32 or 64; K and V^T of one sequence and
+ * head must fit the 160 KB of LDS: L <= 1120 at dh 32, L <= 576 at dh 64;
  * pointers 16-byte aligned, B <= 65535.                                            */
 int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads,
                         int32_t dh, int32_t dtype, float scale, void* out, int32_t device,

@@ -327,3 +327,31 @@ def test_attention_varlen_argument_errors():
     big = torch.zeros((1, 2048, 3 * 64), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_lib.TriStageNativeError):
         attention_varlen(big, torch.full((1,), 2048, dtype=torch.int32, device="cuda"), 1)   # K and V^T do not fit LDS
+
+
+@pytest.mark.parametrize("H,V,shape,types", [(384, 30522, (64, 168), True), (1024, 5000, (7, 33), False), (772, 100, (3, 5), True)])
+def test_fused_embed_layernorm_matches_torch(H, V, shape, types):
+    """ts_embed_layernorm against the torch ops it replaces: (word[ids] + type[tt]) + pos[p] in fp32, layer_norm, cast."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import embed_layernorm
+    g = torch.Generator(device="cuda").manual_seed(H + V)
+    word = torch.randn((V, H), generator=g, device="cuda")
+    pos = torch.randn((514, H), generator=g, device="cuda") * 0.5
+    typ = torch.randn((2, H), generator=g, device="cuda") * 0.1
+    gamma = torch.rand((H,), generator=g, device="cuda") + 0.5
+    beta = torch.randn((H,), generator=g, device="cuda") * 0.1
+    ids = torch.randint(0, V, shape, generator=g, device="cuda")
+    ids[0, 0], ids[-1, -1] = V - 1, 0
+    pid = torch.arange(shape[1], device="cuda")[None, :].expand(*shape) + 2          # a non-contiguous view, like the forward's
+    tt = torch.randint(0, 2, shape, generator=g, device="cuda") if types else None
+    want = F.layer_norm((word[ids] + typ[tt if tt is not None else torch.zeros_like(ids)]) + pos[pid], (H,), gamma, beta, 1e-12)
+    for lp in (torch.bfloat16, torch.float16):
+        y32, ylp = embed_layernorm(ids, pid, tt, word, pos, typ, gamma, beta, 1e-12, lp_dtype=lp)
+        assert y32.shape == shape + (H,) and ylp.dtype == lp
+        assert float((y32 - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+        assert torch.equal(ylp, y32.to(lp))
+    with pytest.raises(ValueError):
+        embed_layernorm(ids, pid, tt, word.half(), pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        embed_layernorm(ids, pid[:, :-1], tt, word, pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)

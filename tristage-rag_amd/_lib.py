@@ -59,6 +59,8 @@ SIGNATURES = {
                                  POINTER(c_int32), c_void_p]),
     "ts_add_layernorm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_void_p]),
+    "ts_embed_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                     c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ts_attention_varlen": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p,
                                       c_int32, c_void_p]),
     "ts_maxsim_release_scratch": (c_int32, [c_int32]),

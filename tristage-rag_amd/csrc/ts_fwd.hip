@@ -10,6 +10,7 @@
 // read x (16-bit or fp32) and the fp32 residual once, write y in fp32 (the next residual) and in the 16-bit type
 // (the next GEMM's input): 12 bytes per element.  One wave per row, the row in registers, two-pass mean / variance.
 #include "ts_common.h"
+#include <initializer_list>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LN_MAX_CHUNKS 8   // 4-element chunks per lane: H <= 2048
@@ -37,59 +38,129 @@ __device__ __forceinline__ uint32_t ln_pack2(float a, float b, int dt) {
   return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
 }
 
-template <int XDT>
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const void* x, const float* res, const float* gamma,
-                                                            const float* beta, float eps, int64_t rows, int H,
-                                                            float* out_f32, void* out_lp, int lp_dt) {
+struct LnParams {
+  const void* x;            // [rows, H] of XDT — or, for the embedding variant, the fp32 word table [V, H]
+  const float* res;         // fp32 [rows, H] or null
+  const float *gamma, *beta;
+  float eps;
+  int64_t rows;
+  int H;
+  float* out_f32;
+  void* out_lp;
+  int lp_dt;
+  // embedding variant: row r = (word[ids[r]] + type[type_ids[r] or 0]) + position[pos_ids[r]]
+  const int64_t *ids, *pos_ids, *type_ids;
+  const float *pos_tab, *typ_tab;
+};
+
+// One row into registers (NCH 4-element chunks per lane).
+template <int XDT, int NCH, bool EMB>
+__device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lane, f32x4 (&v)[NCH]) {
+  if constexpr (EMB) {
+    const int64_t w = p.ids[row] * p.H, ps = p.pos_ids[row] * p.H, t = p.type_ids ? p.type_ids[row] * p.H : 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = (c * 64 + lane) * 4;
+      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < p.H)
+        v[c] = (ln_load4<TS_F32>(p.x, w + e) + *reinterpret_cast<const f32x4*>(p.typ_tab + t + e)) +
+               *reinterpret_cast<const f32x4*>(p.pos_tab + ps + e);
+    }
+  } else {
+    const int64_t base = row * p.H;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = (c * 64 + lane) * 4;
+      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < p.H) {
+        v[c] = ln_load4<XDT>(p.x, base + e);
+        if (p.res) v[c] += *reinterpret_cast<const f32x4*>(p.res + base + e);
+      }
+    }
+  }
+}
+
+// Persistent waves, one row each per iteration; the NEXT row's loads are issued before this row's reductions so that
+// the two dependent shuffle trees do not leave the memory pipe empty.
+template <int XDT, int NCH, bool EMB>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int nch = (H / 4 + 63) / 64;   // chunks per lane (host: <= LN_MAX_CHUNKS)
-  for (int64_t row = wave; row < rows; row += nwaves) {
-    const int64_t base = row * H;
-    f32x4 v[LN_MAX_CHUNKS];
+  const int H = p.H;
+  f32x4 g[NCH], bt[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = (c * 64 + lane) * 4;
+    g[c] = bt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e < H) {
+      g[c] = *reinterpret_cast<const f32x4*>(p.gamma + e);
+      bt[c] = *reinterpret_cast<const f32x4*>(p.beta + e);
+    }
+  }
+  f32x4 v[NCH], nx[NCH];
+  int64_t row = wave;
+  if (row < p.rows) ln_fetch<XDT, NCH, EMB>(p, row, lane, v);
+  while (row < p.rows) {
+    const int64_t next = row + nwaves;
+    if (next < p.rows) ln_fetch<XDT, NCH, EMB>(p, next, lane, nx);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
-      const int e = (c * 64 + lane) * 4;
-      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < nch && e < H) {
-        v[c] = ln_load4<XDT>(x, base + e);
-        if (res) v[c] += *reinterpret_cast<const f32x4*>(res + base + e);
-        sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-      }
-    }
+    for (int c = 0; c < NCH; ++c) sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);   // (chunks beyond H are zeros)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)H;
     float sq = 0.f;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int e = (c * 64 + lane) * 4;
-      if (c < nch && e < H) {
+      if (e < H) {
         const f32x4 d = v[c] - mean;
         sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float rstd = 1.0f / sqrtf(sq / (float)H + eps);
+    const float rstd = 1.0f / sqrtf(sq / (float)H + p.eps);
+    const int64_t base = row * H;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       const int e = (c * 64 + lane) * 4;
-      if (c < nch && e < H) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e), b = *reinterpret_cast<const f32x4*>(beta + e);
-        const f32x4 y = (v[c] - mean) * rstd * g + b;
-        if (out_f32) *reinterpret_cast<f32x4*>(out_f32 + base + e) = y;
-        if (out_lp) {
+      if (e < H) {
+        const f32x4 y = (v[c] - mean) * rstd * g[c] + bt[c];
+        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + base + e) = y;
+        if (p.out_lp) {
           uint2 pk;
-          pk.x = ln_pack2(y[0], y[1], lp_dt);
-          pk.y = ln_pack2(y[2], y[3], lp_dt);
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out_lp) + base + e) = pk;
+          pk.x = ln_pack2(y[0], y[1], p.lp_dt);
+          pk.y = ln_pack2(y[2], y[3], p.lp_dt);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out_lp) + base + e) = pk;
         }
       }
     }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) v[c] = nx[c];
+    row = next;
   }
+}
+
+template <int XDT, bool EMB>
+static int ln_launch(const LnParams& p, hipStream_t s) {
+  const int nch = (p.H / 4 + 63) / 64;
+  const int64_t want = (p.rows + 3) / 4;
+  const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
+  if (nch <= 1) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 1, EMB>), dim3(grid), dim3(256), 0, s, p);
+  else if (nch <= 2) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 2, EMB>), dim3(grid), dim3(256), 0, s, p);
+  else if (nch <= 4) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 4, EMB>), dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((add_layernorm_kernel<XDT, LN_MAX_CHUNKS, EMB>), dim3(grid), dim3(256), 0, s, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { ts_set_error("layernorm launch failed: %s", hipGetErrorString(e)); return TS_ERR_HIP; }
+  return TS_OK;
+}
+
+static bool ln_aligned(std::initializer_list<const void*> ps) {
+  uintptr_t al = 0;
+  for (const void* q : ps) al |= reinterpret_cast<uintptr_t>(q);
+  return (al & 15) == 0;
 }
 
 extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
@@ -105,27 +176,47 @@ extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* res
     ts_set_error("add_layernorm: H = %d not supported (multiple of 4, <= %d)", H, LN_MAX_CHUNKS * 256);
     return TS_ERR_UNSUPPORTED;
   }
-  const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gamma) |
-                       reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out_f32) | reinterpret_cast<uintptr_t>(out_lp);
-  if (al & 15) {
+  if (!ln_aligned({x, residual, gamma, beta, out_f32, out_lp})) {
     ts_set_error("add_layernorm: pointers must be 16-byte aligned");
     return TS_ERR_UNSUPPORTED;
   }
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (prev != device) TS_HIP(hipSetDevice(device));
-  const int64_t want = (rows + 3) / 4;
-  const int grid = (int)(want < 256 * 16 ? want : 256 * 16);
+  LnParams p = {};
+  p.x = x; p.res = residual; p.gamma = gamma; p.beta = beta; p.eps = eps; p.rows = rows; p.H = H;
+  p.out_f32 = out_f32; p.out_lp = out_lp; p.lp_dt = lp_dtype;
   hipStream_t s = (hipStream_t)stream;
-  switch (x_dtype) {
-    case TS_F32: hipLaunchKernelGGL(add_layernorm_kernel<TS_F32>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, eps, rows, H, out_f32, out_lp, lp_dtype); break;
-    case TS_F16: hipLaunchKernelGGL(add_layernorm_kernel<TS_F16>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, eps, rows, H, out_f32, out_lp, lp_dtype); break;
-    default: hipLaunchKernelGGL(add_layernorm_kernel<TS_BF16>, dim3(grid), dim3(256), 0, s, x, residual, gamma, beta, eps, rows, H, out_f32, out_lp, lp_dtype); break;
-  }
-  const hipError_t e = hipGetLastError();
+  const int st = x_dtype == TS_F32 ? ln_launch<TS_F32, false>(p, s) : x_dtype == TS_F16 ? ln_launch<TS_F16, false>(p, s)
+                                                                                        : ln_launch<TS_BF16, false>(p, s);
   if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
-  if (e != hipSuccess) { ts_set_error("add_layernorm launch failed: %s", hipGetErrorString(e)); return TS_ERR_HIP; }
-  return TS_OK;
+  return st;
+}
+
+extern "C" int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids, const float* word_tab,
+                                  const float* pos_tab, const float* typ_tab, const float* gamma, const float* beta, float eps,
+                                  int64_t rows, int32_t H, float* out_f32, void* out_lp, int32_t lp_dtype, int32_t device,
+                                  void* stream) {
+  if (rows == 0) return TS_OK;
+  if (!ids || !pos_ids || !word_tab || !pos_tab || !typ_tab || !gamma || !beta || rows < 0 || H <= 0 || (!out_f32 && !out_lp) ||
+      (out_lp && lp_dtype != TS_F16 && lp_dtype != TS_BF16)) {
+    ts_set_error("bad arguments to embed_layernorm");
+    return TS_ERR_INVALID;
+  }
+  if ((H % 4) != 0 || H > LN_MAX_CHUNKS * 256 || !ln_aligned({word_tab, pos_tab, typ_tab, gamma, beta, out_f32, out_lp})) {
+    ts_set_error("embed_layernorm: H = %d (multiple of 4, <= %d) or pointer alignment (16 bytes) not supported", H, LN_MAX_CHUNKS * 256);
+    return TS_ERR_UNSUPPORTED;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != device) TS_HIP(hipSetDevice(device));
+  LnParams p = {};
+  p.x = word_tab; p.gamma = gamma; p.beta = beta; p.eps = eps; p.rows = rows; p.H = H;
+  p.out_f32 = out_f32; p.out_lp = out_lp; p.lp_dt = lp_dtype;
+  p.ids = ids; p.pos_ids = pos_ids; p.type_ids = type_ids; p.pos_tab = pos_tab; p.typ_tab = typ_tab;
+  const int st = ln_launch<TS_F32, true>(p, (hipStream_t)stream);
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  return st;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -164,30 +255,43 @@ struct AttnParams {
   float scale;
 };
 
+// Lanes l and l^32 exchange through v_permlane32_swap: swap(a, b) leaves a = [a.lo32, b.lo32], b = [a.hi32, b.hi32].
+__device__ __forceinline__ float fw_max_halves(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float fw_sum_halves(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+#define ATTN_KPAD 8   // K rows in LDS are DH + 8 elements apart: the 16-byte fragment reads of 16 lanes hit 64 distinct banks
+
 template <int DT, int DH>
 __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
   const int len = min(p.lens[b], p.L);
   if (len <= 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int H = p.heads * DH;
+  constexpr int KS = DH + ATTN_KPAD;
   const int64_t tstride = 3 * (int64_t)H;                          // elements between consecutive tokens
   const uint16_t* base = p.qkv + (int64_t)b * p.L * tstride + head * DH;
   const int ntile = (len + 31) >> 5, lp = ntile * 32;
   const int vts = lp + 8;                                          // row stride of V^T (elements): +8 against bank conflicts
-  uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);                // [lp][DH]
-  uint16_t* Vt = Ks + (size_t)lp * DH;                             // [DH][vts]
+  uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);                // [lp][KS]
+  uint16_t* Vt = Ks + (size_t)lp * KS;                             // [DH][vts]
   // ---- stage K (row-major) and V (transposed); rows beyond len are zeros
-  for (int i = tid; i < lp * (DH / 8); i += 256) {
+  for (int i = tid; i < lp * (DH / 8); i += nthr) {
     const int t = i / (DH / 8), c = i % (DH / 8);
     fw_u4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
     if (t < len) {
       kv = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + H + 8 * c);
       vv = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + 2 * H + 8 * c);
     }
-    *reinterpret_cast<fw_u4*>(Ks + (size_t)t * DH + 8 * c) = kv;
+    *reinterpret_cast<fw_u4*>(Ks + (size_t)t * KS + 8 * c) = kv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Vt[(size_t)(8 * c + 2 * j) * vts + t] = (uint16_t)(vv[j] & 0xffffu);
@@ -195,15 +299,16 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
     }
   }
   __syncthreads();
+  const float c2 = p.scale * 1.44269504088896341f;                 // softmax in base 2: exp(x*scale - m) = exp2(x*c2 - m2)
 
-  for (int qt = wave; qt < ntile; qt += 4) {
+  for (int qt = wave; qt < ntile; qt += nwave) {
     // ---- this tile's 32 queries as the B operand of S^T = K Q^T: lane (query r, half h) holds Q[query][16 s + 8h ..+8]
     const int qrow = min(qt * 32 + r, len - 1);                    // (rows beyond len repeat the last one; never stored)
     fw_u4 qf[DH / 16];
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s)
       qf[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
-    float m = -3.0e38f, l = 0.f;
+    float m = -3.0e38f, l = 0.f;                                   // running max (base-2 scaled) and sum of this lane's query
     fw_f16v oacc[DH / 32];
 #pragma unroll
     for (int d = 0; d < DH / 32; ++d)
@@ -216,48 +321,45 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
       for (int x = 0; x < 16; ++x) s[x] = 0.f;
 #pragma unroll
       for (int st = 0; st < DH / 16; ++st) {
-        const fw_u4 kf = *reinterpret_cast<const fw_u4*>(Ks + (size_t)(kt * 32 + r) * DH + 16 * st + 8 * h);
+        const fw_u4 kf = *reinterpret_cast<const fw_u4*>(Ks + (size_t)(kt * 32 + r) * KS + 16 * st + 8 * h);
         s = fw_mma<DT>(kf, qf[st], s);                             // rows = keys, column = this lane's query
       }
-      // ---- scale, mask the keys beyond len, online softmax (per lane: one query; its other half sits in lane ^ 32)
-      float mx = -3.0e38f;
+      if (kt == ntile - 1 && (len & 31)) {                         // keys beyond len (last tile only)
 #pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int key = kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        s[x] = key < len ? s[x] * p.scale : -3.0e38f;
-        mx = fmaxf(mx, s[x]);
+        for (int x = 0; x < 16; ++x)
+          if (kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h >= len) s[x] = -3.0e38f;
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __expf(m - mn);
+      // ---- online softmax (per lane: one query; the other half of its keys sits in lane ^ 32)
+      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+      for (int x = 4; x < 16; x += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[x], s[x + 1]), fmaxf(s[x + 2], s[x + 3])));
+      mx = fw_max_halves(mx) * c2;                                 // (c2 > 0)
+      if (__any(mx > m)) {                                         // some query's maximum moved: rescale what is accumulated
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        l *= alpha;
+        m = mn;
+#pragma unroll
+        for (int d = 0; d < DH / 32; ++d)
+#pragma unroll
+          for (int x = 0; x < 16; ++x) oacc[d][x] *= alpha;
+      }
       float rs = 0.f;
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
-        s[x] = __expf(s[x] - mn);                                  // (masked keys: exp(-huge) = 0)
+        s[x] = __builtin_amdgcn_exp2f(fmaf(s[x], c2, -m));         // (masked keys: exp2(-huge) = 0)
         rs += s[x];
       }
-      rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = mn;
-#pragma unroll
-      for (int d = 0; d < DH / 32; ++d)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) oacc[d][x] *= alpha;
+      l += fw_sum_halves(rs);
       // ---- O^T += V^T P^T, two k steps of 16 keys.  B operand: lane (query, h) needs P[query][16 s2 + 8h + j]; the
-      // accumulator holds keys 16 s2 + {0..3 | 8..11} (+4h): registers are exchanged with lane ^ 32
+      // accumulator holds keys 16 s2 + {0..3 | 8..11} (+4h): packed to 16 bit, then lanes l and l^32 swap halves
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        float v0[4], v1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = s[8 * s2 + i], hi = s[8 * s2 + 4 + i];
-          const float got = __shfl_xor(h ? lo : hi, 32, 64);       // each lane sends what its partner needs
-          v0[i] = h ? got : lo;
-          v1[i] = h ? hi : got;
-        }
-        fw_u4 pf;
-        pf[0] = fw_pack2<DT>(v0[0], v0[1]); pf[1] = fw_pack2<DT>(v0[2], v0[3]);
-        pf[2] = fw_pack2<DT>(v1[0], v1[1]); pf[3] = fw_pack2<DT>(v1[2], v1[3]);
+        const uint32_t l0 = fw_pack2<DT>(s[8 * s2], s[8 * s2 + 1]), l1 = fw_pack2<DT>(s[8 * s2 + 2], s[8 * s2 + 3]);
+        const uint32_t h0 = fw_pack2<DT>(s[8 * s2 + 4], s[8 * s2 + 5]), h1 = fw_pack2<DT>(s[8 * s2 + 6], s[8 * s2 + 7]);
+        const auto e0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);   // [0]: keys 0..1 | 8..9   [1]: 4..5 | 12..13
+        const auto e1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);   // [0]: keys 2..3 | 10..11 [1]: 6..7 | 14..15
+        const fw_u4 pf = {e0[0], e1[0], e0[1], e1[1]};
 #pragma unroll
         for (int d = 0; d < DH / 32; ++d) {
           const fw_u4 vf = *reinterpret_cast<const fw_u4*>(Vt + (size_t)(32 * d + r) * vts + kt * 32 + 16 * s2 + 8 * h);
@@ -283,12 +385,22 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   }
 }
 
+static size_t attn_lds_bytes(int L, int dh) {
+  const int lp = (L + 31) / 32 * 32;
+  return ((size_t)lp * (dh + ATTN_KPAD) + (size_t)dh * (lp + 8)) * 2;
+}
+
 template <int DT, int DH>
 static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
   auto kern = attn_varlen_kernel<DT, DH>;
   static TsDeviceOnce lds_attr;
   TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
-  hipLaunchKernelGGL(kern, dim3(p.heads, B), dim3(256), lds, s, p);
+  // waves per workgroup: each takes query tiles w, w + waves, ...; the fewest waves that keep the number of rounds of
+  // four (6 tiles: 3 waves x 2 rounds, not 4 waves of which two idle in the second round)
+  const int ntile = (p.L + 31) / 32, rounds = (ntile + 3) / 4;
+  int waves = 4;
+  while (waves > 1 && (ntile + waves - 2) / (waves - 1) == rounds) --waves;
+  hipLaunchKernelGGL(kern, dim3(p.heads, B), dim3(64 * waves), lds, s, p);
   TS_HIP(hipGetLastError());
   return TS_OK;
 }
@@ -300,8 +412,7 @@ extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t
     ts_set_error("bad arguments to attention_varlen");
     return TS_ERR_INVALID;
   }
-  const int lp = (L + 31) / 32 * 32;
-  const size_t lds = ((size_t)lp * dh + (size_t)dh * (lp + 8)) * 2;
+  const size_t lds = attn_lds_bytes(L, dh);
   if ((dh != 32 && dh != 64) || lds > 160 * 1024 || B > 65535 ||
       ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15)) {
     ts_set_error("attention_varlen: head dimension %d / length %d / alignment not supported", dh, L);

@@ -742,10 +742,8 @@ class LeanBertClassifier:
         else:   # RoBERTa family: positions count the non-padding tokens, offset by the padding index
             nonpad = (input_ids != self.pad_idx).to(torch.int64)
             pos = torch.cumsum(nonpad, dim=1) * nonpad + self.pad_idx
-        x = self.word[input_ids] + self.typ[token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids)]
-        x = (x + self.pos[pos]).float()
-        H, nh = x.shape[-1], self.heads
-        fused = (self.fused_layernorm and self.cd in (torch.bfloat16, torch.float16) and x.is_cuda and H % 4 == 0 and H <= 2048)
+        H, nh = int(self.word.shape[-1]), self.heads
+        fused = (self.fused_layernorm and self.cd in (torch.bfloat16, torch.float16) and input_ids.is_cuda and H % 4 == 0 and H <= 2048)
         if fused:
             from .index import add_layernorm   # HIP kernel (raises without the library)
 
@@ -755,10 +753,15 @@ class LeanBertClassifier:
             def add_ln(new, old, ln):          # the same arithmetic in torch ops (16-bit + fp32 -> fp32 add, fp32 LayerNorm, cast)
                 y = F.layer_norm(new + old if old is not None else new, (H,), ln[0], ln[1], ln[2])
                 return y, y.to(cd)
-        x, xb = add_ln(x, None, self.emb_ln)
+        if fused and all(t.dtype == torch.float32 and t.is_contiguous() for t in (self.word, self.pos, self.typ)):
+            from .index import embed_layernorm   # gather + sum + LayerNorm + cast in one pass
+            x, xb = embed_layernorm(input_ids, pos, token_type_ids, self.word, self.pos, self.typ, *self.emb_ln, lp_dtype=cd)
+        else:
+            x = self.word[input_ids] + self.typ[token_type_ids if token_type_ids is not None else torch.zeros_like(input_ids)]
+            x, xb = add_ln((x + self.pos[pos]).float(), None, self.emb_ln)
         mask = lens = abuf = None
         dh = H // nh
-        if (fused and self.fused_attention and dh in (32, 64) and B <= 65535 and (-(-L // 32) * 32 * 4 + 16) * dh <= 160 * 1024):
+        if (fused and self.fused_attention and dh in (32, 64) and B <= 65535 and L <= (1120 if dh == 32 else 576)):
             # right-padded batch (what tokenizers and PairAssembler produce): every sequence attends over its own tokens
             lens = (lengths.to(torch.int32) if lengths is not None
                     else torch.full((B,), L, dtype=torch.int32, device=x.device) if attention_mask is None

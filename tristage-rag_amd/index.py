@@ -475,3 +475,29 @@ def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = N
                                        _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5),
                                        ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out
+
+
+def embed_layernorm(ids, pos_ids, type_ids, word, pos, typ, gamma, beta, eps: float, lp_dtype=None, want_f32: bool = True):
+    """The embedding layer of a BERT-family model in one pass on the GPU (ts_embed_layernorm):
+    ``LayerNorm((word[ids] + typ[type_ids]) + pos[pos_ids])``; ids / pos_ids / type_ids int64 of one shape (type_ids None =
+    type 0), tables fp32 [*, H].  Indices must be in range (the caller's tokenizer guarantees it).  Returns (fp32 or None,
+    ``lp_dtype`` copy or None) of shape ids.shape + (H,)."""
+    torch = _torch()
+    lib = _lib.load()
+    H = int(word.shape[-1])
+    tabs = [t.detach() for t in (word, pos, typ, gamma, beta)]
+    if any(t.dtype != torch.float32 or not t.is_contiguous() or t.device != ids.device for t in tabs):
+        raise ValueError("embedding tables and LayerNorm parameters must be contiguous float32 on the ids' device")
+    idx = [ids.contiguous(), pos_ids.contiguous(), type_ids.contiguous() if type_ids is not None else None]
+    if any(t is not None and (t.dtype != torch.int64 or t.shape != ids.shape) for t in idx):
+        raise ValueError("ids, pos_ids and type_ids must be int64 of one shape")
+    shape = tuple(ids.shape) + (H,)
+    out32 = torch.empty(shape, dtype=torch.float32, device=ids.device) if want_f32 else None
+    outlp = torch.empty(shape, dtype=lp_dtype, device=ids.device) if lp_dtype is not None else None
+    dev = ids.device.index
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(lib.ts_embed_layernorm(ptr(idx[0]), ptr(idx[1]), ptr(idx[2]), ptr(tabs[0]), ptr(tabs[1]), ptr(tabs[2]),
+                                      ptr(tabs[3]), ptr(tabs[4]), float(eps), ids.numel(), H, ptr(out32), ptr(outlp),
+                                      _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev,
+                                      ctypes.c_void_p(_stream_ptr(dev))))
+    return out32, outlp
