@@ -246,6 +246,14 @@ __device__ __forceinline__ fw_f16v fw_mma(const fw_u4& a, const fw_u4& b, fw_f16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fw_bf8, a), __builtin_bit_cast(fw_bf8, b), c, 0, 0, 0);
 }
 template <int DT> __device__ __forceinline__ uint32_t fw_pack2(float a, float b) { return ln_pack2(a, b, DT); }
+typedef float fw_f2 __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ uint32_t fw_pack2v(fw_f2 v) {     // one v_cvt_pk_{bf16,f16}_f32
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  if constexpr (DT == TS_F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+}
+
 
 struct AttnParams {
   const uint16_t* qkv;   // [B, L, 3, heads, DH] 16-bit
@@ -283,19 +291,38 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   const int vts = lp + 8;                                          // row stride of V^T (elements): +8 against bank conflicts
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);                // [lp][KS]
   uint16_t* Vt = Ks + (size_t)lp * KS;                             // [DH][vts]
-  // ---- stage K (row-major) and V (transposed); rows beyond len are zeros
-  for (int i = tid; i < lp * (DH / 8); i += nthr) {
-    const int t = i / (DH / 8), c = i % (DH / 8);
-    fw_u4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-    if (t < len) {
-      kv = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + H + 8 * c);
-      vv = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + 2 * H + 8 * c);
-    }
-    *reinterpret_cast<fw_u4*>(Ks + (size_t)t * KS + 8 * c) = kv;
+  // ---- the first query tile's loads go out before everything else (see below)
+  fw_u4 qnext[DH / 16];
+  {
+    const int qrow = min(wave * 32 + r, len - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Vt[(size_t)(8 * c + 2 * j) * vts + t] = (uint16_t)(vv[j] & 0xffffu);
-      Vt[(size_t)(8 * c + 2 * j + 1) * vts + t] = (uint16_t)(vv[j] >> 16);
+    for (int s = 0; s < DH / 16; ++s)
+      qnext[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
+  }
+  // ---- stage K (row-major) and V (transposed); rows beyond len are zeros.  Four chunks per thread in flight
+  const int nchunk = lp * (DH / 8);
+  for (int i0 = tid; i0 < nchunk; i0 += 4 * nthr) {
+    fw_u4 kv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthr, t = i / (DH / 8), c = i % (DH / 8);
+      kv[u] = vv[u] = fw_u4{0u, 0u, 0u, 0u};
+      if (i < nchunk && t < len) {
+        kv[u] = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + H + 8 * c);
+        vv[u] = *reinterpret_cast<const fw_u4*>(base + (int64_t)t * tstride + 2 * H + 8 * c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nthr, t = i / (DH / 8), c = i % (DH / 8);
+      if (i < nchunk) {
+        *reinterpret_cast<fw_u4*>(Ks + (size_t)t * KS + 8 * c) = kv[u];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Vt[(size_t)(8 * c + 2 * j) * vts + t] = (uint16_t)(vv[u][j] & 0xffffu);
+          Vt[(size_t)(8 * c + 2 * j + 1) * vts + t] = (uint16_t)(vv[u][j] >> 16);
+        }
+      }
     }
   }
   __syncthreads();
@@ -303,11 +330,17 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
 
   for (int qt = wave; qt < ntile; qt += nwave) {
     // ---- this tile's 32 queries as the B operand of S^T = K Q^T: lane (query r, half h) holds Q[query][16 s + 8h ..+8]
-    const int qrow = min(qt * 32 + r, len - 1);                    // (rows beyond len repeat the last one; never stored)
+    // (rows beyond len repeat the last one; never stored.)  The NEXT tile's rows are requested now and used a whole key
+    // loop later
     fw_u4 qf[DH / 16];
 #pragma unroll
-    for (int s = 0; s < DH / 16; ++s)
-      qf[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
+    for (int s = 0; s < DH / 16; ++s) qf[s] = qnext[s];
+    if (qt + nwave < ntile) {
+      const int qrow = min((qt + nwave) * 32 + r, len - 1);
+#pragma unroll
+      for (int s = 0; s < DH / 16; ++s)
+        qnext[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
+    }
     float m = -3.0e38f, l = 0.f;                                   // running max (base-2 scaled) and sum of this lane's query
     fw_f16v oacc[DH / 32];
 #pragma unroll
@@ -327,13 +360,23 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
       if (kt == ntile - 1 && (len & 31)) {                         // keys beyond len (last tile only)
 #pragma unroll
         for (int x = 0; x < 16; ++x)
-          if (kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h >= len) s[x] = -3.0e38f;
+          if (kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h >= len) s[x] = -1.0e30f;   // (times c2 below: stays finite)
       }
-      // ---- online softmax (per lane: one query; the other half of its keys sits in lane ^ 32)
-      float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+      // ---- online softmax (per lane: one query; the other half of its keys sits in lane ^ 32).  Packed fp32 arithmetic
+      // (v_pk_fma / v_pk_add), v_max3, v_cvt_pk: this loop is bound by the vector ALU, not by the matrix cores
+      // (the scaled scores first: products are canonical numbers, so the maxima below fold into v_max3 without a
+      // quieting v_max per operand — and no hand-written instruction reads a matrix-core result, whose wait states
+      // only the compiler's own instructions get)
 #pragma unroll
-      for (int x = 4; x < 16; x += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[x], s[x + 1]), fmaxf(s[x + 2], s[x + 3])));
-      mx = fw_max_halves(mx) * c2;                                 // (c2 > 0)
+      for (int x = 0; x < 16; x += 2) {
+        const fw_f2 t = fw_f2{s[x], s[x + 1]} * c2;
+        s[x] = t[0];
+        s[x + 1] = t[1];
+      }
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+      for (int x = 3; x < 15; x += 2) mx = fmaxf(fmaxf(mx, s[x]), s[x + 1]);
+      mx = fw_max_halves(fmaxf(mx, s[15]));
       if (__any(mx > m)) {                                         // some query's maximum moved: rescale what is accumulated
         const float mn = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -344,21 +387,22 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
 #pragma unroll
           for (int x = 0; x < 16; ++x) oacc[d][x] *= alpha;
       }
-      float rs = 0.f;
+      fw_f2 rs2 = {0.f, 0.f};
+      uint32_t pk[8];
 #pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        s[x] = __builtin_amdgcn_exp2f(fmaf(s[x], c2, -m));         // (masked keys: exp2(-huge) = 0)
-        rs += s[x];
+      for (int x = 0; x < 16; x += 2) {
+        const fw_f2 t = fw_f2{s[x], s[x + 1]} - m;                 // (masked keys: exp2(-huge) = 0)
+        const fw_f2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+        rs2 += e;
+        pk[x >> 1] = fw_pack2v<DT>(e);
       }
-      l += fw_sum_halves(rs);
+      l += fw_sum_halves(rs2[0] + rs2[1]);
       // ---- O^T += V^T P^T, two k steps of 16 keys.  B operand: lane (query, h) needs P[query][16 s2 + 8h + j]; the
       // accumulator holds keys 16 s2 + {0..3 | 8..11} (+4h): packed to 16 bit, then lanes l and l^32 swap halves
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const uint32_t l0 = fw_pack2<DT>(s[8 * s2], s[8 * s2 + 1]), l1 = fw_pack2<DT>(s[8 * s2 + 2], s[8 * s2 + 3]);
-        const uint32_t h0 = fw_pack2<DT>(s[8 * s2 + 4], s[8 * s2 + 5]), h1 = fw_pack2<DT>(s[8 * s2 + 6], s[8 * s2 + 7]);
-        const auto e0 = __builtin_amdgcn_permlane32_swap(l0, h0, false, false);   // [0]: keys 0..1 | 8..9   [1]: 4..5 | 12..13
-        const auto e1 = __builtin_amdgcn_permlane32_swap(l1, h1, false, false);   // [0]: keys 2..3 | 10..11 [1]: 6..7 | 14..15
+        const auto e0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2], pk[4 * s2 + 2], false, false);       // [0]: keys 0..1 | 8..9   [1]: 4..5 | 12..13
+        const auto e1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);   // [0]: keys 2..3 | 10..11 [1]: 6..7 | 14..15
         const fw_u4 pf = {e0[0], e1[0], e0[1], e1[1]};
 #pragma unroll
         for (int d = 0; d < DH / 32; ++d) {
