@@ -642,3 +642,35 @@ def test_lean_classifier_forward_equals_the_transformers_module(spec):
     a = m.logits_from_ids(enc)
     m.lean_forward = False
     assert torch.allclose(a, m.logits_from_ids(enc), atol=1e-6)
+
+
+@pytest.mark.parametrize("spec", ["random:tiny", "random:xlmr-large:64:2:4"])
+def test_lean_encoder_forward_equals_the_transformers_module(spec):
+    """encoders.LeanBertEncoder on a bare AutoModel: the last hidden state of the transformers module (fp32 equal, bf16
+    against the module under autocast), and SentenceEncoder.encode / ColBERTScorer._forward only route through it under
+    16-bit autocast on a GPU (here, on the CPU, both keep the module's forward)."""
+    from tristage_rag_amd.encoders import LeanBertEncoder, SentenceEncoder, lean_encoder_for, load_backbone
+    tok, model, _ = load_backbone(spec, "/tmp/ts_models", "base")
+    model.eval()
+    g = torch.Generator().manual_seed(1)
+    B, L = 7, 23
+    ids = torch.randint(1000, 20000, (B, L), generator=g)
+    lens = torch.randint(3, L + 1, (B,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ids = ids * mask + (1 - mask) * int(getattr(model.config, "pad_token_id", 0) or 0)
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask).last_hidden_state
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref16 = model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
+    valid = mask.bool()
+    got = LeanBertEncoder(model, None)(ids, mask)
+    assert got.dtype == torch.float32 and torch.allclose(got[valid], ref[valid], atol=2e-6)
+    got16 = LeanBertEncoder(model, torch.bfloat16)(ids, mask)
+    assert got16.dtype == torch.float32 and float((got16[valid] - ref16[valid]).abs().max()) < 0.05 * float(ref16.abs().max())
+    assert lean_encoder_for(model, torch.bfloat16) is lean_encoder_for(model, torch.bfloat16)      # built once per dtype
+    assert lean_encoder_for(torch.nn.Linear(2, 2), torch.bfloat16) is False                         # no such architecture
+    enc = SentenceEncoder(spec, device="cpu")
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        enc.encode(["a b c", "d"])
+    assert "_ts_lean_encoders" not in enc.model.__dict__                                            # CPU: module forward

@@ -355,3 +355,33 @@ def test_fused_embed_layernorm_matches_torch(H, V, shape, types):
         embed_layernorm(ids, pid, tt, word.half(), pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         embed_layernorm(ids, pid[:, :-1], tt, word, pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
+
+
+def test_stage1_and_stage2_encoders_use_the_written_out_forward_under_amp():
+    """SentenceEncoder.encode and ColBERTScorer._forward under bf16 autocast on the GPU run LeanBertEncoder (HIP
+    embedding / LayerNorm / attention kernels between the GEMMs) for BERT-family models; against the transformers
+    module under the same autocast: embeddings to 2e-2 absolute on unit vectors' raw hidden scale / cosine > 0.999."""
+    import torch
+    from tristage_rag_amd.encoders import SentenceEncoder
+    from tristage_rag_amd.stage2_rescorer import ColBERTScorer, Stage2Config
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(500)]
+    texts = [" ".join(rng.choice(vocab, size=int(n))) for n in rng.integers(1, 120, size=150)] + ["", "w1"]
+    enc = SentenceEncoder("random:bert", device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        lean = enc.encode(texts, batch_size=64, convert_to_tensor=True, normalize_embeddings=True)
+        assert enc.model.__dict__.get("_ts_lean_encoders", {}).get(torch.bfloat16)
+        enc.lean_forward = False
+        ref = enc.encode(texts, batch_size=64, convert_to_tensor=True, normalize_embeddings=True)
+    assert float((lean * ref).sum(1).min()) > 0.999
+    plain = enc.encode(texts[:5], convert_to_tensor=True)               # no autocast: the module's fp32 forward
+    assert plain.dtype == torch.float32
+    s2 = ColBERTScorer(Stage2Config(model_name="random:minilm", device="cuda", use_fp16=True, max_seq_length=64))
+    batch = s2._tokenize_batch(texts[:40])
+    a = s2._forward(batch)
+    assert s2.model.__dict__.get("_ts_lean_encoders", {}).get(torch.bfloat16)
+    s2.lean_forward = False
+    b = s2._forward(batch)
+    valid = batch["attention_mask"].bool()
+    assert a.dtype == b.dtype == torch.float32
+    assert float((a[valid] - b[valid]).abs().max()) < 0.03 * float(b[valid].abs().max())

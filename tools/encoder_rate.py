@@ -13,9 +13,15 @@ import torch
 from tristage_rag_amd.encoders import load_backbone
 
 
-def rate(name, head, batch, seqlen, reps=10):
+def rate(name, head, batch, seqlen, reps=10, lean=False):
     tok, model, _ = load_backbone(name, "/tmp/ts_models", head, **({"num_labels": 1} if head == "seqcls" else {}))
     model.to("cuda").eval()
+    if lean:   # the written-out forward with the library's HIP kernels between the GEMMs (tristage_rag_amd.encoders)
+        from tristage_rag_amd.encoders import LeanBertClassifier, LeanBertEncoder
+        fwd = (LeanBertClassifier if head == "seqcls" else LeanBertEncoder)(model, torch.bfloat16)
+        hf = model
+        model = lambda input_ids, attention_mask: fwd(input_ids, attention_mask)
+        model.named_parameters, model.parameters = hf.named_parameters, hf.parameters
     emb = sum(p.numel() for n, p in model.named_parameters() if "embed" in n)
     params = sum(p.numel() for p in model.parameters()) - emb
     ids = torch.randint(1000, 20000, (batch, seqlen), device="cuda")
@@ -30,13 +36,18 @@ def rate(name, head, batch, seqlen, reps=10):
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     toks = batch * seqlen
-    return {"model": name, "head": head, "batch": batch, "seq_len": seqlen, "non_embedding_params_M": round(params / 1e6, 1),
+    return {"model": name, "head": head, "forward": "lean" if lean else "transformers", "batch": batch, "seq_len": seqlen, "non_embedding_params_M": round(params / 1e6, 1),
             "ms_per_forward": round(dt * 1e3, 3), "tokens_per_s": round(toks / dt), "model_TFLOPs": round(2 * params * toks / dt / 1e12, 1),
             "frac_of_2.5PF_bf16": round(2 * params * toks / dt / 2.5e15, 4)}
 
 
 if __name__ == "__main__":
     out = [rate("random:bert", "base", 64, 128),             # stage-1 document encoding (BERT-base shape)
+           rate("random:bert", "base", 64, 128, lean=True),
+           rate("random:bert", "base", 512, 128),
+           rate("random:bert", "base", 512, 128, lean=True),
+           rate("random:minilm", "seqcls", 1024, 168, lean=True),
+           rate("random:xlmr-large", "seqcls", 100, 256, reps=5, lean=True),
            rate("random:modernbert", "base", 64, 128),       # stage-2 token store build (ModernBERT-base shape)
            rate("random:modernbert", "base", 1, 16),         # stage-2 query forward, batch 1
            rate("random:minilm", "seqcls", 1024, 168),       # stage-3 rerank_many forward

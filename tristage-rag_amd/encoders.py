@@ -363,6 +363,7 @@ class SentenceEncoder:
         self.amp_dtype = amp_dtype
         self.pooling_mode = "mean"
         self.normalize = False
+        self.lean_forward = True      # BERT-family models under 16-bit autocast on a GPU: the written-out forward (LeanBertEncoder)
         self.dense: List[torch.nn.Module] = []
         self.max_seq_length = int(max_seq_length or min(getattr(self.tokenizer, "model_max_length", 512), 512))
         if src:
@@ -438,7 +439,11 @@ class SentenceEncoder:
                         torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
                 hidden = self._graphed(enc["input_ids"], enc["attention_mask"])
             else:
-                hidden = self.model(**enc).last_hidden_state
+                lean = False
+                if self.lean_forward and str(self.device).startswith("cuda") and torch.is_autocast_enabled("cuda"):
+                    lean = lean_encoder_for(self.model, torch.get_autocast_dtype("cuda"))
+                hidden = (lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids")) if lean
+                          else self.model(**enc).last_hidden_state)
             emb = self._pool(hidden.float(), enc["attention_mask"])
             for d in self.dense:
                 emb = d(emb)
@@ -682,26 +687,31 @@ class PairAssembler:
         return out
 
 
-# --------------------------------------------------------------------------- lean BERT-family classifier forward
-class LeanBertClassifier:
-    """The forward of a BERT / RoBERTa / XLM-R sequence-classification model written out in plain torch ops
+# --------------------------------------------------------------------------- lean BERT-family forwards
+class LeanBertEncoder:
+    """The forward of a BERT / RoBERTa / XLM-R encoder (``AutoModel``: last hidden state) written out in plain torch ops
     on the checkpoint's own weights: the arithmetic ``torch.autocast`` performs on the transformers module
     (linears in the compute dtype with outputs in that dtype, residual adds and LayerNorms in fp32, softmax
     inside scaled_dot_product_attention), minus what the module spends around it at 10^5 tokens per batch:
     ONE fused QKV GEMM instead of three (the fp32 LayerNorm output is cast once, not three times), weights
     cast once at construction instead of through the autocast cache, no mask tensor at all for a batch without
     padding, no per-layer Python of the generic module.  ``compute_dtype=None`` runs everything in fp32 and
-    reproduces the module's fp32 forward (tests).  Used by CrossEncoderModel for batched reranking; the
-    per-query paths keep the transformers forward."""
+    reproduces the module's fp32 forward (tests).  With 16-bit compute on a GPU the passes between the GEMMs are
+    the library's HIP kernels: embedding gather + LayerNorm, residual add + LayerNorm + cast, and attention over
+    each sequence's own tokens (ts_embed_layernorm, ts_add_layernorm, ts_attention_varlen).  Used for the batched
+    forwards of all three stages when the model is of this family (SentenceEncoder.encode, ColBERTScorer._forward,
+    CrossEncoderModel through LeanBertClassifier); HIP-graph replays and other architectures keep the transformers
+    forward."""
 
-    def __init__(self, hf_model, compute_dtype=None):
-        cfg = hf_model.config
+    def __init__(self, base, compute_dtype=None):
+        cfg = base.config
         self.kind = cfg.model_type
         if self.kind not in ("bert", "roberta", "xlm-roberta"):
             raise ValueError(f"no lean forward for model type {self.kind!r}")
         if getattr(cfg, "position_embedding_type", "absolute") != "absolute" or cfg.hidden_act not in ("gelu", "gelu_new", "relu"):
             raise ValueError("unsupported BERT variant")
-        base = hf_model.bert if self.kind == "bert" else hf_model.roberta
+        if not hasattr(base, "embeddings") or not hasattr(base, "encoder"):
+            raise ValueError("not a bare encoder module")
         self.cd = compute_dtype
         cd = compute_dtype or torch.float32
         self.fused_layernorm = True   # 16-bit compute on a GPU: residual add + LayerNorm + cast as one HIP pass (ts_add_layernorm)
@@ -723,18 +733,11 @@ class LeanBertClassifier:
                 "w1": l.intermediate.dense.weight.detach().to(cd), "b1": l.intermediate.dense.bias.detach().to(cd),
                 "w2": l.output.dense.weight.detach().to(cd), "b2": l.output.dense.bias.detach().to(cd),
                 "ln2": (l.output.LayerNorm.weight, l.output.LayerNorm.bias, l.output.LayerNorm.eps)})
-        if self.kind == "bert":
-            self.head = [(base.pooler.dense.weight.detach().to(cd), base.pooler.dense.bias.detach().to(cd), True),
-                         (hf_model.classifier.weight.detach().to(cd), hf_model.classifier.bias.detach().to(cd), False)]
-        else:
-            c = hf_model.classifier
-            self.head = [(c.dense.weight.detach().to(cd), c.dense.bias.detach().to(cd), True),
-                         (c.out_proj.weight.detach().to(cd), c.out_proj.bias.detach().to(cd), False)]
-
     @torch.no_grad()
-    def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
-        """``lengths`` (int32 [B], optional): the caller's promise that attention_mask[b] is 1 exactly on the first
-        lengths[b] positions."""
+    def hidden(self, input_ids, attention_mask, token_type_ids=None, lengths=None):
+        """-> (last hidden state float32 [B, L, H], its copy in the compute dtype).  ``lengths`` (int32 [B], optional):
+        the caller's promise that attention_mask[b] is 1 exactly on the first lengths[b] positions.  Rows at padded
+        positions hold finite values of no meaning (as in the module's output)."""
         cd = self.cd or torch.float32
         B, L = input_ids.shape
         if self.kind == "bert":
@@ -786,12 +789,50 @@ class LeanBertClassifier:
             x, xb = add_ln(o, x, p["ln1"])
             f = F.linear(self.act(F.linear(xb, p["w1"], p["b1"])), p["w2"], p["b2"])
             x, xb = add_ln(f, x, p["ln2"])
-        y = xb[:, 0]
+        return x, xb
+
+    def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
+        return self.hidden(input_ids, attention_mask, token_type_ids, lengths)[0]
+
+
+class LeanBertClassifier(LeanBertEncoder):
+    """LeanBertEncoder + the pooler / classification head of a ...ForSequenceClassification checkpoint -> logits."""
+
+    def __init__(self, hf_model, compute_dtype=None):
+        kind = hf_model.config.model_type
+        if kind not in ("bert", "roberta", "xlm-roberta"):
+            raise ValueError(f"no lean forward for model type {kind!r}")
+        base = hf_model.bert if kind == "bert" else hf_model.roberta
+        super().__init__(base, compute_dtype)
+        cd = compute_dtype or torch.float32
+        if kind == "bert":
+            self.head = [(base.pooler.dense.weight.detach().to(cd), base.pooler.dense.bias.detach().to(cd), True),
+                         (hf_model.classifier.weight.detach().to(cd), hf_model.classifier.bias.detach().to(cd), False)]
+        else:
+            c = hf_model.classifier
+            self.head = [(c.dense.weight.detach().to(cd), c.dense.bias.detach().to(cd), True),
+                         (c.out_proj.weight.detach().to(cd), c.out_proj.bias.detach().to(cd), False)]
+
+    @torch.no_grad()
+    def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
+        y = self.hidden(input_ids, attention_mask, token_type_ids, lengths)[1][:, 0]
         for w, b, tanh in self.head:
             y = F.linear(y, w, b)
             if tanh:
                 y = torch.tanh(y)
         return y.float()
+
+
+def lean_encoder_for(model, compute_dtype):
+    """The LeanBertEncoder of a bare encoder module for one compute dtype (built once, kept on the module), or False
+    when the architecture has none."""
+    cache = model.__dict__.setdefault("_ts_lean_encoders", {})
+    if compute_dtype not in cache:
+        try:
+            cache[compute_dtype] = LeanBertEncoder(model, compute_dtype)
+        except Exception:
+            cache[compute_dtype] = False
+    return cache[compute_dtype]
 
 
 # --------------------------------------------------------------------------- cross-encoder

@@ -155,6 +155,11 @@ class ColBERTScorer:
     def _forward(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
         with torch.no_grad():
             if self.use_amp:
+                if getattr(self, "lean_forward", True):
+                    from .encoders import lean_encoder_for   # BERT-family token encoders: the written-out forward
+                    lean = lean_encoder_for(self.model, torch.bfloat16)
+                    if lean:
+                        return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"))
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     return self.model(**enc).last_hidden_state
             return self.model(**enc).last_hidden_state
