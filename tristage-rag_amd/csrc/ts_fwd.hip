@@ -53,14 +53,14 @@ struct LnParams {
   const float *pos_tab, *typ_tab;
 };
 
-// One row into registers (NCH 4-element chunks per lane).
-template <int XDT, int NCH, bool EMB>
-__device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lane, f32x4 (&v)[NCH]) {
+// One row into registers: LPR lanes per row (64, or 32 = two rows per wave), NCH 4-element chunks per lane.
+template <int XDT, int NCH, int LPR, bool EMB>
+__device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lir, f32x4 (&v)[NCH]) {
   if constexpr (EMB) {
     const int64_t w = p.ids[row] * p.H, ps = p.pos_ids[row] * p.H, t = p.type_ids ? p.type_ids[row] * p.H : 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int e = (c * 64 + lane) * 4;
+      const int e = (c * LPR + lir) * 4;
       v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < p.H)
         v[c] = (ln_load4<TS_F32>(p.x, w + e) + *reinterpret_cast<const f32x4*>(p.typ_tab + t + e)) +
@@ -70,7 +70,7 @@ __device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lan
     const int64_t base = row * p.H;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int e = (c * 64 + lane) * 4;
+      const int e = (c * LPR + lir) * 4;
       v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < p.H) {
         v[c] = ln_load4<XDT>(p.x, base + e);
@@ -80,18 +80,20 @@ __device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lan
   }
 }
 
-// Persistent waves, one row each per iteration; the NEXT row's loads are issued before this row's reductions so that
-// the two dependent shuffle trees do not leave the memory pipe empty.
-template <int XDT, int NCH, bool EMB>
+// Persistent waves, 64 / LPR rows each per iteration; the NEXT rows' loads are issued before these rows' reductions so
+// that the two dependent shuffle trees do not leave the memory pipe empty.  LPR = 32 for H <= 384 keeps every lane busy
+// (H = 384 is 96 chunks of 4: three per lane of a half wave).
+template <int XDT, int NCH, int LPR, bool EMB>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
-  const int lane = threadIdx.x & 63;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, lir = lane % LPR, sub = lane / LPR;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6) * RPW;
   const int H = p.H;
   f32x4 g[NCH], bt[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int e = (c * 64 + lane) * 4;
+    const int e = (c * LPR + lir) * 4;
     g[c] = bt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (e < H) {
       g[c] = *reinterpret_cast<const f32x4*>(p.gamma + e);
@@ -99,33 +101,33 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
     }
   }
   f32x4 v[NCH], nx[NCH];
-  int64_t row = wave;
-  if (row < p.rows) ln_fetch<XDT, NCH, EMB>(p, row, lane, v);
+  int64_t row = wave * RPW + sub;
+  if (row < p.rows) ln_fetch<XDT, NCH, LPR, EMB>(p, row, lir, v);
   while (row < p.rows) {
-    const int64_t next = row + nwaves;
-    if (next < p.rows) ln_fetch<XDT, NCH, EMB>(p, next, lane, nx);
+    const int64_t next = row + stride;
+    if (next < p.rows) ln_fetch<XDT, NCH, LPR, EMB>(p, next, lir, nx);
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);   // (chunks beyond H are zeros)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)H;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int e = (c * 64 + lane) * 4;
+      const int e = (c * LPR + lir) * 4;
       if (e < H) {
         const f32x4 d = v[c] - mean;
         sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
     const float rstd = 1.0f / sqrtf(sq / (float)H + p.eps);
     const int64_t base = row * H;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int e = (c * 64 + lane) * 4;
+      const int e = (c * LPR + lir) * 4;
       if (e < H) {
         const f32x4 y = (v[c] - mean) * rstd * g[c] + bt[c];
         if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + base + e) = y;
@@ -145,13 +147,18 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
 
 template <int XDT, bool EMB>
 static int ln_launch(const LnParams& p, hipStream_t s) {
-  const int nch = (p.H / 4 + 63) / 64;
-  const int64_t want = (p.rows + 3) / 4;
+  const int q = p.H / 4;                                   // 4-element chunks per row
+  const bool half = q <= 96;                               // two rows per wave
+  const int nch = half ? (q + 31) / 32 : (q + 63) / 64;
+  const int64_t want = half ? (p.rows + 7) / 8 : (p.rows + 3) / 4;
   const int grid = (int)(want < 256 * 8 ? want : 256 * 8);
-  if (nch <= 1) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 1, EMB>), dim3(grid), dim3(256), 0, s, p);
-  else if (nch <= 2) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 2, EMB>), dim3(grid), dim3(256), 0, s, p);
-  else if (nch <= 4) hipLaunchKernelGGL((add_layernorm_kernel<XDT, 4, EMB>), dim3(grid), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((add_layernorm_kernel<XDT, LN_MAX_CHUNKS, EMB>), dim3(grid), dim3(256), 0, s, p);
+#define LN_GO(NCH, LPR) hipLaunchKernelGGL((add_layernorm_kernel<XDT, NCH, LPR, EMB>), dim3(grid), dim3(256), 0, s, p)
+  if (half) {
+    if (nch <= 1) LN_GO(1, 32); else if (nch <= 2) LN_GO(2, 32); else LN_GO(3, 32);
+  } else {
+    if (nch <= 2) LN_GO(2, 64); else if (nch <= 4) LN_GO(4, 64); else LN_GO(LN_MAX_CHUNKS, 64);
+  }
+#undef LN_GO
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ts_set_error("layernorm launch failed: %s", hipGetErrorString(e)); return TS_ERR_HIP; }
   return TS_OK;
