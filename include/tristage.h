@@ -237,10 +237,18 @@ int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t
  *   statistics and arithmetic, like torch.layer_norm);
  * x [rows, H] of x_dtype; residual fp32 [rows, H] or NULL; gamma / beta fp32 [H];
  * y is written as fp32 (out_f32, may be NULL) and / or in lp_dtype (out_lp, TS_F16 or
- * TS_BF16, may be NULL).  H a multiple of 4, <= 2048; pointers 16-byte aligned (device). */
+ * TS_BF16, may be NULL).  beta may be NULL (a LayerNorm without bias).  H a multiple of
+ * 4, <= 2048; pointers 16-byte aligned (device).                                    */
 int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
                      const float* beta, float eps, int64_t rows, int32_t H, float* out_f32,
                      void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
+
+/* The same pass for a pre-LN model (ModernBERT, the reference's default stage-2 token
+ * encoder, src/stage2_rescorer.py:30): out_sum (fp32, may be NULL) receives x + residual
+ * — the residual stream — and out_lp the normalised row for the next GEMM.           */
+int ts_add_prenorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
+                   const float* beta, float eps, int64_t rows, int32_t H, float* out_sum,
+                   void* out_lp, int32_t lp_dtype, int32_t device, void* stream);
 
 /* The embedding layer of those models the same way: row r of the output is
  *   LayerNorm((word[ids[r]] + type[type_ids[r]]) + position[pos_ids[r]]) * gamma + beta
@@ -263,10 +271,25 @@ int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t
  * softmax statistics and accumulation, probabilities rounded to dtype before the
  * P V product (as flash attention does).  dh 32 or 64; K and V^T of one sequence and
  * head must fit the 160 KB of LDS: L <= 1120 at dh 32, L <= 576 at dh 64;
- * pointers 16-byte aligned, B <= 65535.                                            */
+ * pointers 16-byte aligned, B <= 65535.  window > 0: query q only sees the keys k with
+ * |q - k| <= window (the bidirectional sliding window of ModernBERT's local layers:
+ * window = local_attention / 2); 0 = all keys.                                      */
 int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads,
-                        int32_t dh, int32_t dtype, float scale, void* out, int32_t device,
-                        void* stream);
+                        int32_t dh, int32_t dtype, float scale, int32_t window, void* out,
+                        int32_t device, void* stream);
+
+/* Rotary position embedding of the q and k thirds of qkv [B, L, 3, heads, dh] in place:
+ * x <- x * cos + rotate_half(x) * sin with fp32 tables cos / sin [L, dh] (row = token
+ * position), computed in fp32 like transformers' apply_rotary_pos_emb (products and sum
+ * each rounded, no fused multiply-add), rounded once to dtype.  dh a multiple of 8.   */
+int ts_rope_inplace(void* qkv, int32_t dtype, const float* cos_tab, const float* sin_tab, int64_t B,
+                    int32_t L, int32_t heads, int32_t dh, int32_t device, void* stream);
+
+/* Gated GELU of ModernBertMLP: u [rows, 2 I] -> out [rows, I] = gelu(u[:, :I]) * u[:, I:]
+ * (erf GELU in fp32 rounded to dtype, then the product rounded to dtype: the two
+ * roundings of the two torch ops).  I a multiple of 8.                               */
+int ts_geglu(const void* u, int32_t dtype, int64_t rows, int32_t I, void* out, int32_t device,
+             void* stream);
 
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */

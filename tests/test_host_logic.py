@@ -674,3 +674,34 @@ def test_lean_encoder_forward_equals_the_transformers_module(spec):
     with torch.autocast("cpu", dtype=torch.bfloat16):
         enc.encode(["a b c", "d"])
     assert "_ts_lean_encoders" not in enc.model.__dict__                                            # CPU: module forward
+
+
+def test_lean_modernbert_forward_equals_the_transformers_module():
+    """encoders.LeanModernBertEncoder (pre-LN blocks, rotary embedding, local window |q-k| <= 64 on the sliding
+    layers, gated GELU) against transformers' ModernBertModel: fp32 equal on the valid tokens of a padded batch longer
+    than the window, bf16 against the module under autocast; lean_encoder_for picks it by model type."""
+    from tristage_rag_amd.encoders import LeanModernBertEncoder, lean_encoder_for, load_backbone
+    tok, model, _ = load_backbone("random:modernbert:64:4:2", "/tmp/ts_models", "base")
+    model.eval()
+    assert {l.attention_type for l in model.layers} == {"full_attention", "sliding_attention"}
+    g = torch.Generator().manual_seed(2)
+    B, L = 5, 150
+    ids = torch.randint(1000, 20000, (B, L), generator=g)
+    lens = torch.tensor([L, 1, 64, 66, 131])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ids = ids * mask
+    with torch.no_grad():
+        ref = model(input_ids=ids, attention_mask=mask).last_hidden_state
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ref16 = model(input_ids=ids, attention_mask=mask).last_hidden_state.float()
+    valid = mask.bool()
+    lean = LeanModernBertEncoder(model, None)
+    assert lean.window == 64
+    got = lean(ids, mask)
+    assert got.dtype == torch.float32 and torch.allclose(got[valid], ref[valid], atol=5e-6)
+    got16 = LeanModernBertEncoder(model, torch.bfloat16)(ids, mask)
+    assert float((got16[valid] - ref16[valid]).abs().max()) < 0.05 * float(ref16[valid].abs().max())
+    # an unpadded batch without a mask tensor
+    full = LeanModernBertEncoder(model, None)(ids[:1], None)
+    assert torch.allclose(full, ref[:1], atol=5e-6)
+    assert isinstance(lean_encoder_for(model, None), LeanModernBertEncoder)

@@ -385,3 +385,91 @@ def test_stage1_and_stage2_encoders_use_the_written_out_forward_under_amp():
     valid = batch["attention_mask"].bool()
     assert a.dtype == b.dtype == torch.float32
     assert float((a[valid] - b[valid]).abs().max()) < 0.03 * float(b[valid].abs().max())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_rope_geglu_prenorm_and_window_kernels_match_torch(dt):
+    """The four kernels of the ModernBERT forward against the torch ops they replace."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import add_layernorm, attention_varlen, geglu, rope_inplace
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    step = 2.0 ** (-8 if dt == "bf16" else -11)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, L, nh, dh = 6, 200, 3, 64
+    H = nh * dh
+    # rotary embedding, transformers' formula in fp32, one rounding: bit-equal
+    qkv = torch.randn((B, L, 3 * H), generator=g, device="cuda").to(tdt)
+    ang = torch.rand((L, dh // 2), generator=g, device="cuda") * 6.28
+    cos, sin = torch.cat((ang.cos(), ang.cos()), -1).contiguous(), torch.cat((ang.sin(), ang.sin()), -1).contiguous()
+    v5 = qkv.view(B, L, 3, nh, dh)
+    half = lambda z: torch.cat((-z[..., dh // 2:], z[..., : dh // 2]), dim=-1)
+    want = qkv.clone().view(B, L, 3, nh, dh)
+    for j in (0, 1):
+        z = v5[:, :, j].float()
+        want[:, :, j] = ((z * cos[None, :, None]) + (half(z) * sin[None, :, None])).to(tdt)
+    got = rope_inplace(qkv.clone(), cos, sin, nh).view(B, L, 3, nh, dh)
+    assert torch.equal(got, want)
+    # gated GELU: two roundings like the two torch ops
+    u = (torch.randn((B, L, 2 * 1152), generator=g, device="cuda") * 2).to(tdt)
+    a, b = u.chunk(2, dim=-1)
+    ref = F.gelu(a) * b
+    out = geglu(u)
+    assert out.shape == ref.shape and float((out.float() - ref.float()).abs().max()) <= 2 * step * float(ref.abs().max())
+    assert float((out != ref).float().mean()) < 0.01               # (erf of the two libraries: rare last-bit differences)
+    # pre-LN: residual stream out, normalised 16-bit copy, no bias
+    x = torch.randn((B * L, 768), generator=g, device="cuda").to(tdt)
+    res = torch.randn((B * L, 768), generator=g, device="cuda")
+    gamma = torch.rand((768,), generator=g, device="cuda") + 0.5
+    s32, ylp = add_layernorm(x, res, gamma, None, 1e-5, lp_dtype=tdt, prenorm=True)
+    assert torch.equal(s32, x.float() + res)
+    assert torch.equal(ylp, F.layer_norm(x.float() + res, (768,), gamma, None, 1e-5).to(tdt)) or \
+        float((ylp.float() - F.layer_norm(x.float() + res, (768,), gamma, None, 1e-5)).abs().max()) <= step * 8
+    y32, _ = add_layernorm(x, res, gamma, None, 1e-5, lp_dtype=tdt)
+    assert float((y32 - F.layer_norm(x.float() + res, (768,), gamma, None, 1e-5)).abs().max()) < 1e-5
+    # local attention: |q - k| <= window, with padding
+    lens = torch.tensor([L, 1, 64, 66, 131, 199], dtype=torch.int32, device="cuda")
+    q, k, v = (v5[:, :, j].transpose(1, 2) for j in range(3))
+    valid = torch.arange(L, device="cuda")[None, :] < lens[:, None]
+    t = torch.arange(L, device="cuda")
+    for window in (64, 10, 500):
+        near = (t[:, None] - t[None, :]).abs() <= window
+        s = (q.float() @ k.float().transpose(-1, -2)) * dh ** -0.5
+        s = s.masked_fill(~(valid[:, None, None, :] & near[None, None]), float("-inf"))
+        want_a = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, L, H)
+        got_a = attention_varlen(qkv, lens, nh, window=window)
+        assert float((got_a.float() - want_a)[valid].abs().max()) <= 3 * step * float(want_a[valid].abs().max())
+
+
+def test_lean_modernbert_on_gpu_matches_module_under_autocast():
+    """ColBERTScorer._forward with the reference's default stage-2 architecture (ModernBERT-base shape) under bf16
+    AMP runs LeanModernBertEncoder with the HIP kernels; against the transformers module under the same autocast."""
+    import torch
+    from tristage_rag_amd.stage2_rescorer import ColBERTScorer, Stage2Config
+    from tristage_rag_amd.encoders import LeanModernBertEncoder
+    rng = np.random.default_rng(5)
+    vocab = [f"w{i}" for i in range(500)]
+    texts = [" ".join(rng.choice(vocab, size=int(n))) for n in rng.integers(1, 180, size=40)] + ["", "w1"]
+    s2 = ColBERTScorer(Stage2Config(model_name="random:modernbert", device="cuda", use_fp16=True, max_seq_length=192))
+    batch = s2._tokenize_batch(texts)
+    assert batch["input_ids"].shape[1] > 130                        # beyond the local window
+    a = s2._forward(batch)
+    lean = s2.model.__dict__.get("_ts_lean_encoders", {}).get(torch.bfloat16)
+    assert isinstance(lean, LeanModernBertEncoder)
+    s2.lean_forward = False
+    b = s2._forward(batch)
+    valid = batch["attention_mask"].bool()
+    assert a.dtype == b.dtype == torch.float32
+    err = float((a[valid] - b[valid]).abs().max()) / float(b[valid].abs().max())
+    assert err < 0.04, err                                          # 22 layers of bf16 GEMMs in different shapes
+    cosine = torch.nn.functional.cosine_similarity(a[valid], b[valid], dim=-1)
+    assert float(cosine.min()) > 0.998
+    # the torch fallback of the same class (holes in the mask) agrees too
+    holed = {k: v.clone() for k, v in batch.items()}
+    holed["attention_mask"][:, 2] = 0
+    s2.lean_forward = True
+    c = s2._forward(holed)
+    s2.lean_forward = False
+    d = s2._forward(holed)
+    hv = holed["attention_mask"].bool()
+    assert float((c[hv] - d[hv]).abs().max()) / float(d[hv].abs().max()) < 0.04

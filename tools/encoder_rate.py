@@ -17,8 +17,8 @@ def rate(name, head, batch, seqlen, reps=10, lean=False):
     tok, model, _ = load_backbone(name, "/tmp/ts_models", head, **({"num_labels": 1} if head == "seqcls" else {}))
     model.to("cuda").eval()
     if lean:   # the written-out forward with the library's HIP kernels between the GEMMs (tristage_rag_amd.encoders)
-        from tristage_rag_amd.encoders import LeanBertClassifier, LeanBertEncoder
-        fwd = (LeanBertClassifier if head == "seqcls" else LeanBertEncoder)(model, torch.bfloat16)
+        from tristage_rag_amd.encoders import LeanBertClassifier, lean_encoder_for
+        fwd = LeanBertClassifier(model, torch.bfloat16) if head == "seqcls" else lean_encoder_for(model, torch.bfloat16)
         hf = model
         model = lambda input_ids, attention_mask: fwd(input_ids, attention_mask)
         model.named_parameters, model.parameters = hf.named_parameters, hf.parameters
@@ -47,6 +47,10 @@ if __name__ == "__main__":
            rate("random:bert", "base", 512, 128),
            rate("random:bert", "base", 512, 128, lean=True),
            rate("random:minilm", "seqcls", 1024, 168, lean=True),
+           rate("random:modernbert", "base", 64, 128, lean=True),
+           rate("random:modernbert", "base", 512, 128),
+           rate("random:modernbert", "base", 512, 128, lean=True),
+           rate("random:modernbert", "base", 1, 16, lean=True),
            rate("random:xlmr-large", "seqcls", 100, 256, reps=5, lean=True),
            rate("random:modernbert", "base", 64, 128),       # stage-2 token store build (ModernBERT-base shape)
            rate("random:modernbert", "base", 1, 16),         # stage-2 query forward, batch 1

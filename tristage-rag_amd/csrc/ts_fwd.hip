@@ -48,6 +48,7 @@ struct LnParams {
   float* out_f32;
   void* out_lp;
   int lp_dt;
+  int prenorm;              // out_f32 receives x + residual (the residual stream of a pre-LN model) instead of y
   // embedding variant: row r = (word[ids[r]] + type[type_ids[r] or 0]) + position[pos_ids[r]]
   const int64_t *ids, *pos_ids, *type_ids;
   const float *pos_tab, *typ_tab;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
     g[c] = bt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (e < H) {
       g[c] = *reinterpret_cast<const f32x4*>(p.gamma + e);
-      bt[c] = *reinterpret_cast<const f32x4*>(p.beta + e);
+      if (p.beta) bt[c] = *reinterpret_cast<const f32x4*>(p.beta + e);
     }
   }
   f32x4 v[NCH], nx[NCH];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
       const int e = (c * LPR + lir) * 4;
       if (e < H) {
         const f32x4 y = (v[c] - mean) * rstd * g[c] + bt[c];
-        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + base + e) = y;
+        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + base + e) = p.prenorm ? v[c] : y;
         if (p.out_lp) {
           uint2 pk;
           pk.x = ln_pack2(y[0], y[1], p.lp_dt);
@@ -170,11 +171,11 @@ static bool ln_aligned(std::initializer_list<const void*> ps) {
   return (al & 15) == 0;
 }
 
-extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
-                                const float* beta, float eps, int64_t rows, int32_t H, float* out_f32, void* out_lp,
-                                int32_t lp_dtype, int32_t device, void* stream) {
+static int add_layernorm_impl(const void* x, int32_t x_dtype, const float* residual, const float* gamma, const float* beta,
+                              float eps, int64_t rows, int32_t H, float* out_f32, void* out_lp, int32_t lp_dtype, int prenorm,
+                              int32_t device, void* stream) {
   if (rows == 0) return TS_OK;
-  if (!x || !gamma || !beta || rows < 0 || H <= 0 || (!out_f32 && !out_lp) ||
+  if (!x || !gamma || rows < 0 || H <= 0 || (!out_f32 && !out_lp) ||
       (x_dtype != TS_F32 && x_dtype != TS_F16 && x_dtype != TS_BF16) || (out_lp && lp_dtype != TS_F16 && lp_dtype != TS_BF16)) {
     ts_set_error("bad arguments to add_layernorm");
     return TS_ERR_INVALID;
@@ -192,7 +193,7 @@ extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* res
   if (prev != device) TS_HIP(hipSetDevice(device));
   LnParams p = {};
   p.x = x; p.res = residual; p.gamma = gamma; p.beta = beta; p.eps = eps; p.rows = rows; p.H = H;
-  p.out_f32 = out_f32; p.out_lp = out_lp; p.lp_dt = lp_dtype;
+  p.out_f32 = out_f32; p.out_lp = out_lp; p.lp_dt = lp_dtype; p.prenorm = prenorm;
   hipStream_t s = (hipStream_t)stream;
   const int st = x_dtype == TS_F32 ? ln_launch<TS_F32, false>(p, s) : x_dtype == TS_F16 ? ln_launch<TS_F16, false>(p, s)
                                                                                         : ln_launch<TS_BF16, false>(p, s);
@@ -200,12 +201,24 @@ extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* res
   return st;
 }
 
+extern "C" int ts_add_layernorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma,
+                                const float* beta, float eps, int64_t rows, int32_t H, float* out_f32, void* out_lp,
+                                int32_t lp_dtype, int32_t device, void* stream) {
+  return add_layernorm_impl(x, x_dtype, residual, gamma, beta, eps, rows, H, out_f32, out_lp, lp_dtype, 0, device, stream);
+}
+
+extern "C" int ts_add_prenorm(const void* x, int32_t x_dtype, const float* residual, const float* gamma, const float* beta,
+                              float eps, int64_t rows, int32_t H, float* out_sum, void* out_lp, int32_t lp_dtype,
+                              int32_t device, void* stream) {
+  return add_layernorm_impl(x, x_dtype, residual, gamma, beta, eps, rows, H, out_sum, out_lp, lp_dtype, 1, device, stream);
+}
+
 extern "C" int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids, const float* word_tab,
                                   const float* pos_tab, const float* typ_tab, const float* gamma, const float* beta, float eps,
                                   int64_t rows, int32_t H, float* out_f32, void* out_lp, int32_t lp_dtype, int32_t device,
                                   void* stream) {
   if (rows == 0) return TS_OK;
-  if (!ids || !pos_ids || !word_tab || !pos_tab || !typ_tab || !gamma || !beta || rows < 0 || H <= 0 || (!out_f32 && !out_lp) ||
+  if (!ids || !pos_ids || !word_tab || !pos_tab || !typ_tab || !gamma || rows < 0 || H <= 0 || (!out_f32 && !out_lp) ||
       (out_lp && lp_dtype != TS_F16 && lp_dtype != TS_BF16)) {
     ts_set_error("bad arguments to embed_layernorm");
     return TS_ERR_INVALID;
@@ -268,6 +281,7 @@ struct AttnParams {
   uint16_t* out;         // [B, L, heads*DH]
   int L, heads;
   float scale;
+  int window;            // > 0: query q sees key k only if |q - k| <= window (ModernBERT's local layers); 0 = all keys
 };
 
 // Lanes l and l^32 exchange through v_permlane32_swap: swap(a, b) leaves a = [a.lo32, b.lo32], b = [a.hi32, b.hi32].
@@ -355,7 +369,10 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) oacc[d][x] = 0.f;
 
-    for (int kt = 0; kt < ntile; ++kt) {
+    // key tiles this query tile can see at all (a window leaves 2 * window / 32 + 3 of them at most)
+    const int kt_lo = p.window > 0 ? max(0, (qt * 32 - p.window) >> 5) : 0;
+    const int kt_hi = p.window > 0 ? min(ntile - 1, (qt * 32 + 31 + p.window) >> 5) : ntile - 1;
+    for (int kt = kt_lo; kt <= kt_hi; ++kt) {
       fw_f16v s;
 #pragma unroll
       for (int x = 0; x < 16; ++x) s[x] = 0.f;
@@ -368,6 +385,14 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
 #pragma unroll
         for (int x = 0; x < 16; ++x)
           if (kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h >= len) s[x] = -1.0e30f;   // (times c2 below: stays finite)
+      }
+      if (p.window > 0 && (kt * 32 + 31 - qt * 32 > p.window || qt * 32 + 31 - kt * 32 > p.window)) {   // tile straddles the window edge
+        const int q = qt * 32 + r;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int dist = kt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h - q;
+          if (dist > p.window || -dist > p.window) s[x] = -1.0e30f;
+        }
       }
       // ---- online softmax (per lane: one query; the other half of its keys sits in lane ^ 32).  Packed fp32 arithmetic
       // (v_pk_fma / v_pk_add), v_max3, v_cvt_pk: this loop is bound by the vector ALU, not by the matrix cores
@@ -457,9 +482,9 @@ static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
 }
 
 extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads, int32_t dh,
-                                   int32_t dtype, float scale, void* out, int32_t device, void* stream) {
+                                   int32_t dtype, float scale, int32_t window, void* out, int32_t device, void* stream) {
   if (B == 0 || L == 0) return TS_OK;
-  if (!qkv || !lens || !out || B < 0 || L < 0 || heads <= 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
+  if (!qkv || !lens || !out || B < 0 || L < 0 || heads <= 0 || window < 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
     ts_set_error("bad arguments to attention_varlen");
     return TS_ERR_INVALID;
   }
@@ -473,10 +498,134 @@ extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t
   (void)hipGetDevice(&prev);
   if (prev != device) TS_HIP(hipSetDevice(device));
   AttnParams p;
-  p.qkv = (const uint16_t*)qkv; p.lens = lens; p.out = (uint16_t*)out; p.L = L; p.heads = heads; p.scale = scale;
+  p.qkv = (const uint16_t*)qkv; p.lens = lens; p.out = (uint16_t*)out; p.L = L; p.heads = heads; p.scale = scale; p.window = window;
   int st;
   if (dtype == TS_F16) st = dh == 32 ? launch_attn<TS_F16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_F16, 64>(p, B, lds, (hipStream_t)stream);
   else st = dh == 32 ? launch_attn<TS_BF16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_BF16, 64>(p, B, lds, (hipStream_t)stream);
   if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   return st;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rotary position embedding on the q and k thirds of a fused projection, in place, and the gated GELU of the MLP
+// (ModernBERT: the default stage-2 token encoder of the reference, src/stage2_rescorer.py:30, through AutoModel).
+// Both restate transformers' arithmetic: rotation in fp32 from fp32 cos / sin tables — two products and a sum, each
+// rounded, no fused multiply-add — then one rounding to the 16-bit type; gelu(x) = (x * 0.5) * (1 + erf(x / sqrt 2))
+// in fp32 rounded to 16 bit, times the gate rounded again.
+#pragma clang fp contract(off)
+template <int DT> __device__ __forceinline__ float fw_to_f32(uint16_t v) {
+  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __uint_as_float((uint32_t)v << 16);
+}
+template <int DT> __device__ __forceinline__ uint16_t fw_from_f32(float v) {
+  if constexpr (DT == TS_F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
+  else return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rope_kernel(uint16_t* qkv, const float* cosv, const float* sinv, int64_t tokens, int L,
+                                                   int heads, int dh) {
+  // one thread: 4 consecutive d of the first half and their partners in the second half, for q and for k
+  const int per_head = dh / 8;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= tokens * heads * per_head) return;
+  const int c = (int)(i % per_head), head = (int)((i / per_head) % heads);
+  const int64_t tok = i / ((int64_t)per_head * heads);
+  const int t = (int)(tok % L), d0 = 4 * c, half = dh / 2;
+  const float4 cs = *reinterpret_cast<const float4*>(cosv + (int64_t)t * dh + d0);
+  const float4 sn = *reinterpret_cast<const float4*>(sinv + (int64_t)t * dh + d0);
+  const float4 cs2 = *reinterpret_cast<const float4*>(cosv + (int64_t)t * dh + half + d0);
+  const float4 sn2 = *reinterpret_cast<const float4*>(sinv + (int64_t)t * dh + half + d0);
+  const float cf[4] = {cs.x, cs.y, cs.z, cs.w}, sf[4] = {sn.x, sn.y, sn.z, sn.w};
+  const float cg[4] = {cs2.x, cs2.y, cs2.z, cs2.w}, sg[4] = {sn2.x, sn2.y, sn2.z, sn2.w};
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    uint16_t* row = qkv + (tok * 3 + which) * (int64_t)heads * dh + (int64_t)head * dh;
+    uint2 a = *reinterpret_cast<const uint2*>(row + d0), b = *reinterpret_cast<const uint2*>(row + half + d0);
+    uint16_t av[4] = {(uint16_t)a.x, (uint16_t)(a.x >> 16), (uint16_t)a.y, (uint16_t)(a.y >> 16)};
+    uint16_t bv[4] = {(uint16_t)b.x, (uint16_t)(b.x >> 16), (uint16_t)b.y, (uint16_t)(b.y >> 16)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x1 = fw_to_f32<DT>(av[j]), x2 = fw_to_f32<DT>(bv[j]);
+      const float lo = (x1 * cf[j]) + ((-x2) * sf[j]);      // q * cos + rotate_half(q) * sin, first half
+      const float hi = (x2 * cg[j]) + (x1 * sg[j]);         // ... second half
+      av[j] = fw_from_f32<DT>(lo);
+      bv[j] = fw_from_f32<DT>(hi);
+    }
+    a.x = av[0] | ((uint32_t)av[1] << 16); a.y = av[2] | ((uint32_t)av[3] << 16);
+    b.x = bv[0] | ((uint32_t)bv[1] << 16); b.y = bv[2] | ((uint32_t)bv[3] << 16);
+    *reinterpret_cast<uint2*>(row + d0) = a;
+    *reinterpret_cast<uint2*>(row + half + d0) = b;
+  }
+}
+
+extern "C" int ts_rope_inplace(void* qkv, int32_t dtype, const float* cos_tab, const float* sin_tab, int64_t B, int32_t L,
+                               int32_t heads, int32_t dh, int32_t device, void* stream) {
+  if (B == 0 || L == 0) return TS_OK;
+  if (!qkv || !cos_tab || !sin_tab || B < 0 || L < 0 || heads <= 0 || dh <= 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
+    ts_set_error("bad arguments to rope_inplace");
+    return TS_ERR_INVALID;
+  }
+  if ((dh % 8) != 0 || !ln_aligned({qkv, cos_tab, sin_tab})) {
+    ts_set_error("rope_inplace: head dimension %d (multiple of 8) or pointer alignment (16 bytes) not supported", dh);
+    return TS_ERR_UNSUPPORTED;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != device) TS_HIP(hipSetDevice(device));
+  const int64_t n = B * L * heads * (dh / 8);
+  const int64_t grid = (n + 255) / 256;
+  if (dtype == TS_F16) hipLaunchKernelGGL(rope_kernel<TS_F16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, cos_tab, sin_tab, B * L, L, heads, dh);
+  else hipLaunchKernelGGL(rope_kernel<TS_BF16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (uint16_t*)qkv, cos_tab, sin_tab, B * L, L, heads, dh);
+  const hipError_t e = hipGetLastError();
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) { ts_set_error("rope launch failed: %s", hipGetErrorString(e)); return TS_ERR_HIP; }
+  return TS_OK;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void geglu_kernel(const uint16_t* u, uint16_t* out, int64_t rows, int I) {
+  const int per_row = I / 8;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const int64_t row = i / per_row;
+  const int c = (int)(i % per_row);
+  const fw_u4 a = *reinterpret_cast<const fw_u4*>(u + row * 2 * I + 8 * c);
+  const fw_u4 g = *reinterpret_cast<const fw_u4*>(u + row * 2 * I + I + 8 * c);
+  fw_u4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float x = fw_to_f32<DT>((uint16_t)(a[j] >> (16 * k))), gt = fw_to_f32<DT>((uint16_t)(g[j] >> (16 * k)));
+      const float act = fw_to_f32<DT>(fw_from_f32<DT>((x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f))));
+      w |= (uint32_t)fw_from_f32<DT>(act * gt) << (16 * k);
+    }
+    o[j] = w;
+  }
+  *reinterpret_cast<fw_u4*>(out + row * I + 8 * c) = o;
+}
+
+extern "C" int ts_geglu(const void* u, int32_t dtype, int64_t rows, int32_t I, void* out, int32_t device, void* stream) {
+  if (rows == 0 || I == 0) return TS_OK;
+  if (!u || !out || rows < 0 || I < 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
+    ts_set_error("bad arguments to geglu");
+    return TS_ERR_INVALID;
+  }
+  if ((I % 8) != 0 || !ln_aligned({u, out})) {
+    ts_set_error("geglu: width %d (multiple of 8) or pointer alignment (16 bytes) not supported", I);
+    return TS_ERR_UNSUPPORTED;
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (prev != device) TS_HIP(hipSetDevice(device));
+  const int64_t grid = (rows * (I / 8) + 255) / 256;
+  if (dtype == TS_F16) hipLaunchKernelGGL(geglu_kernel<TS_F16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u, (uint16_t*)out, rows, I);
+  else hipLaunchKernelGGL(geglu_kernel<TS_BF16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)u, (uint16_t*)out, rows, I);
+  const hipError_t e = hipGetLastError();
+  if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+  if (e != hipSuccess) { ts_set_error("geglu launch failed: %s", hipGetErrorString(e)); return TS_ERR_HIP; }
+  return TS_OK;
 }

@@ -823,13 +823,126 @@ class LeanBertClassifier(LeanBertEncoder):
         return y.float()
 
 
+class LeanModernBertEncoder:
+    """The forward of a ModernBERT encoder (the reference's default stage-2 token encoder, GTE-ModernColBERT:
+    src/stage2_rescorer.py:30) written out the same way: pre-LN blocks, fused Wqkv, rotary embedding computed in fp32
+    from the module's own inverse frequencies, global layers and local layers with the bidirectional window
+    ``|q - k| <= local_attention / 2``, gated-GELU MLP, final LayerNorm — the arithmetic transformers performs under
+    ``torch.autocast`` (linears and attention in the compute dtype, LayerNorms and the residual stream in fp32).  The
+    module launches ~40 small kernels per layer; here a layer is four GEMMs and five HIP kernels (ts_rope_inplace,
+    ts_attention_varlen with its window, ts_add_prenorm twice, ts_geglu).  ``compute_dtype=None``: fp32 torch ops
+    (tests)."""
+
+    def __init__(self, base, compute_dtype=None):
+        cfg = base.config
+        if cfg.model_type != "modernbert" or not hasattr(base, "layers") or not hasattr(base, "rotary_emb"):
+            raise ValueError("not a ModernBERT encoder module")
+        if getattr(cfg, "hidden_activation", "gelu") != "gelu":
+            raise ValueError("unsupported ModernBERT activation")
+        self.kind = "modernbert"
+        self.cd = compute_dtype
+        cd = compute_dtype or torch.float32
+        self.fused = True             # 16-bit compute on a GPU: the HIP kernels named above
+        self.heads = int(cfg.num_attention_heads)
+        self.window = int(cfg.sliding_window)
+        self.rotary = base.rotary_emb
+        emb = base.embeddings
+        self.tok = emb.tok_embeddings.weight
+        ln = lambda m: None if isinstance(m, torch.nn.Identity) else (m.weight, m.bias, m.eps)
+        lin = lambda m: (m.weight.detach().to(cd).contiguous(), m.bias.detach().to(cd) if m.bias is not None else None)
+        self.emb_ln = ln(emb.norm)
+        self.final_ln = ln(base.final_norm)
+        self.layers = [{"ln1": ln(l.attn_norm), "qkv": lin(l.attn.Wqkv), "o": lin(l.attn.Wo), "ln2": ln(l.mlp_norm),
+                        "wi": lin(l.mlp.Wi), "wo": lin(l.mlp.Wo), "type": l.attention_type} for l in base.layers]
+        if any(p["ln1"] is None for p in self.layers[1:]):
+            raise ValueError("unexpected ModernBERT layout")
+        self._rope = {}
+
+    def _tables(self, L: int, device):
+        """cos / sin [L, head_dim] float32 per layer type, from the module's rotary embedding (positions 0..L-1)."""
+        key = (L, str(device))
+        if key not in self._rope:
+            pos = torch.arange(L, device=device)[None, :]
+            probe = torch.empty(0, dtype=torch.float32, device=device)
+            self._rope[key] = {t: tuple(v[0].float().contiguous() for v in self.rotary(probe, pos, t))
+                               for t in {p["type"] for p in self.layers}}
+        return self._rope[key]
+
+    @torch.no_grad()
+    def hidden(self, input_ids, attention_mask, token_type_ids=None, lengths=None):
+        cd = self.cd or torch.float32
+        B, L = input_ids.shape
+        H, nh = int(self.tok.shape[-1]), self.heads
+        dh = H // nh
+        dev = input_ids.device
+        fused = (self.fused and self.cd in (torch.bfloat16, torch.float16) and input_ids.is_cuda and H % 4 == 0 and H <= 2048
+                 and dh in (32, 64) and B <= 65535 and L <= (1120 if dh == 32 else 576))
+        lens = None
+        if fused:
+            from .index import add_layernorm, attention_varlen, geglu, rope_inplace
+            lens = (lengths.to(torch.int32) if lengths is not None
+                    else torch.full((B,), L, dtype=torch.int32, device=dev) if attention_mask is None
+                    else attention_mask.sum(1, dtype=torch.int32))
+            if lengths is None and attention_mask is not None and not bool(
+                    (attention_mask.to(torch.bool) == (torch.arange(L, device=dev)[None, :] < lens[:, None])).all()):
+                fused, lens = False, None           # holes or left padding: torch ops below
+
+        def norm(new, old, ln, pre):
+            """pre: (old + new, LayerNorm of it in the compute dtype); else (LayerNorm(old + new) fp32, its copy)."""
+            if fused:
+                return add_layernorm(new, old, ln[0], ln[1], ln[2], lp_dtype=cd, prenorm=pre)
+            t = new + old if old is not None else new
+            y = F.layer_norm(t.float(), (H,), ln[0], ln[1], ln[2])
+            return (t, y.to(cd)) if pre else (y, y.to(cd))
+        x, xb = norm(self.tok[input_ids], None, self.emb_ln, False)
+        tables = self._tables(L, dev)
+        masks = {}
+        if not fused:
+            valid = attention_mask.to(torch.bool) if attention_mask is not None else torch.ones((B, L), dtype=torch.bool, device=dev)
+            t = torch.arange(L, device=dev)
+            near = (t[:, None] - t[None, :]).abs() <= self.window
+            masks = {"full_attention": valid[:, None, None, :], "sliding_attention": valid[:, None, None, :] & near[None, None]}
+        else:
+            abuf = torch.zeros((B, L, H), dtype=cd, device=dev)
+        n = len(self.layers)
+        for i, p in enumerate(self.layers):
+            qkv = F.linear(xb, *p["qkv"])
+            cos, sin = tables[p["type"]]
+            if fused:
+                rope_inplace(qkv, cos, sin, nh)
+                a = attention_varlen(qkv, lens, nh, out=abuf, window=self.window if p["type"] == "sliding_attention" else 0)
+            else:
+                q, k, v = (qkv.view(B, L, 3, nh, dh)[:, :, j].transpose(1, 2) for j in range(3))
+                half = lambda z: torch.cat((-z[..., dh // 2:], z[..., : dh // 2]), dim=-1)
+                q, k = ((z.float() * cos[None, None]) + (half(z.float()) * sin[None, None]) for z in (q, k))
+                a = F.scaled_dot_product_attention(q.to(cd), k.to(cd), v, attn_mask=masks[p["type"]]).transpose(1, 2).reshape(B, L, H)
+            o = F.linear(a, *p["o"])
+            x, hb = norm(o, x, p["ln2"], True)
+            u = F.linear(hb, *p["wi"])
+            if fused:
+                g = geglu(u)
+            else:
+                inp, gate = u.chunk(2, dim=-1)
+                g = F.gelu(inp) * gate
+            f = F.linear(g, *p["wo"])
+            if i + 1 < n:
+                x, xb = norm(f, x, self.layers[i + 1]["ln1"], True)
+            else:
+                x, xb = norm(f, x, self.final_ln, False)
+        return x, xb
+
+    def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
+        return self.hidden(input_ids, attention_mask, token_type_ids, lengths)[0]
+
+
 def lean_encoder_for(model, compute_dtype):
     """The LeanBertEncoder of a bare encoder module for one compute dtype (built once, kept on the module), or False
     when the architecture has none."""
     cache = model.__dict__.setdefault("_ts_lean_encoders", {})
     if compute_dtype not in cache:
+        kind = getattr(getattr(model, "config", None), "model_type", None)
         try:
-            cache[compute_dtype] = LeanBertEncoder(model, compute_dtype)
+            cache[compute_dtype] = (LeanModernBertEncoder if kind == "modernbert" else LeanBertEncoder)(model, compute_dtype)
         except Exception:
             cache[compute_dtype] = False
     return cache[compute_dtype]

@@ -429,10 +429,12 @@ def maxsim_indexed_batch(q_packed, q_offsets, store, starts, lens, cand_offsets,
     return out
 
 
-def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32: bool = True):
+def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32: bool = True, prenorm: bool = False):
     """``LayerNorm(x + residual) * gamma + beta`` over the last dimension in ONE pass on the GPU (ts_add_layernorm):
-    x [..., H] (fp32 / fp16 / bf16), residual fp32 of the same shape or None, gamma / beta fp32 [H].
-    Returns (y as fp32 or None, y in ``lp_dtype`` or None) — the next residual and the next GEMM's input."""
+    x [..., H] (fp32 / fp16 / bf16), residual fp32 of the same shape or None, gamma fp32 [H], beta fp32 [H] or None.
+    Returns (y as fp32 or None, y in ``lp_dtype`` or None) — the next residual and the next GEMM's input.
+    ``prenorm=True`` (ts_add_prenorm, pre-LN models): the fp32 result is ``x + residual`` — the residual stream — and the
+    ``lp_dtype`` one its LayerNorm."""
     torch = _torch()
     lib = _lib.load()
     H = int(x.shape[-1])
@@ -442,24 +444,22 @@ def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32:
         residual = residual.contiguous()
         if residual.dtype != torch.float32 or residual.shape != x.shape:
             raise ValueError("residual must be float32 with x's shape")
-    gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+    gamma = gamma.detach().contiguous()
+    beta = beta.detach().contiguous() if beta is not None else None
     out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
     outlp = torch.empty(x.shape, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
     dev = x.device.index
-    _lib.check(lib.ts_add_layernorm(ctypes.c_void_p(x.data_ptr()), _tensor_dtype(x),
-                                    ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
-                                    ctypes.c_void_p(gamma.data_ptr()), ctypes.c_void_p(beta.data_ptr()), float(eps), rows, H,
-                                    ctypes.c_void_p(out32.data_ptr()) if out32 is not None else None,
-                                    ctypes.c_void_p(outlp.data_ptr()) if outlp is not None else None,
-                                    _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev,
-                                    ctypes.c_void_p(_stream_ptr(dev))))
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    fn = lib.ts_add_prenorm if prenorm else lib.ts_add_layernorm
+    _lib.check(fn(ptr(x), _tensor_dtype(x), ptr(residual), ptr(gamma), ptr(beta), float(eps), rows, H, ptr(out32), ptr(outlp),
+                  _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out32, outlp
 
 
-def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None):
+def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None, window: int = 0):
     """Self-attention of a right-padded batch on the GPU (ts_attention_varlen): ``qkv`` [B, L, 3*heads*dh] (fp16 / bf16,
     the fused projection's output, read in place), ``lens`` int32 [B] on the device.  Returns [B, L, heads*dh]; rows at
-    padded positions are zeros (``out`` given: left as they are)."""
+    padded positions are zeros (``out`` given: left as they are).  ``window`` > 0: keys within that distance only."""
     torch = _torch()
     lib = _lib.load()
     B, L, W = (int(v) for v in qkv.shape)
@@ -472,8 +472,40 @@ def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = N
         out = torch.zeros((B, L, heads * dh), dtype=qkv.dtype, device=qkv.device)
     dev = qkv.device.index
     _lib.check(lib.ts_attention_varlen(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lens.data_ptr()), B, L, heads, dh,
-                                       _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5),
+                                       _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5), int(window),
                                        ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+    return out
+
+
+def rope_inplace(qkv, cos, sin, heads: int):
+    """Rotary position embedding of the q and k thirds of ``qkv`` [B, L, 3*heads*dh] (fp16 / bf16) in place
+    (ts_rope_inplace); ``cos`` / ``sin`` float32 [L, dh]."""
+    torch = _torch()
+    lib = _lib.load()
+    B, L, W = (int(v) for v in qkv.shape)
+    dh = W // (3 * heads)
+    if W != 3 * heads * dh or not qkv.is_contiguous():
+        raise ValueError("qkv must be contiguous [B, L, 3 * heads * head_dim]")
+    for t in (cos, sin):
+        if t.dtype != torch.float32 or tuple(t.shape) != (L, dh) or not t.is_contiguous() or t.device != qkv.device:
+            raise ValueError("cos / sin must be contiguous float32 [L, head_dim] on qkv's device")
+    dev = qkv.device.index
+    _lib.check(lib.ts_rope_inplace(ctypes.c_void_p(qkv.data_ptr()), _tensor_dtype(qkv), ctypes.c_void_p(cos.data_ptr()),
+                                   ctypes.c_void_p(sin.data_ptr()), B, L, heads, dh, dev, ctypes.c_void_p(_stream_ptr(dev))))
+    return qkv
+
+
+def geglu(u):
+    """``gelu(u[..., :I]) * u[..., I:]`` for u [..., 2 I] (fp16 / bf16) in one pass on the GPU (ts_geglu)."""
+    torch = _torch()
+    lib = _lib.load()
+    if not u.is_contiguous() or u.shape[-1] % 2:
+        raise ValueError("u must be contiguous with an even last dimension")
+    I = int(u.shape[-1]) // 2
+    out = torch.empty(tuple(u.shape[:-1]) + (I,), dtype=u.dtype, device=u.device)
+    dev = u.device.index
+    _lib.check(lib.ts_geglu(ctypes.c_void_p(u.data_ptr()), _tensor_dtype(u), u.numel() // (2 * I), I,
+                            ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out
 
 
