@@ -205,6 +205,36 @@ def _autocast(device: str, enabled: bool, dtype=torch.bfloat16):
 
 
 # --------------------------------------------------------------------------- hipGraph replay
+def _prefix_lengths(enc, tokenizer):
+    """int32 [B] token counts of a tokenizer batch (still on the host) when its mask is a prefix mask — right padding,
+    the tokenizers' default — else None.  Handed to the written-out forwards so that they need not inspect the mask on
+    the device (a host sync per forward)."""
+    if getattr(tokenizer, "padding_side", "right") != "right" or "attention_mask" not in enc:
+        return None
+    m = enc["attention_mask"]
+    if not isinstance(m, torch.Tensor) or m.is_cuda or m.dim() != 2:
+        return None
+    lens = m.sum(1)
+    if not bool((m.bool() == (torch.arange(m.shape[1])[None, :] < lens[:, None])).all()):
+        return None
+    return lens.to(torch.int32)
+
+
+def _lean_for_graph(model, amp_dtype, classifier: bool):
+    """The written-out forward to capture instead of the transformers module (16-bit AMP, supported family), or None."""
+    if amp_dtype not in (torch.bfloat16, torch.float16):
+        return None
+    if not classifier:
+        return lean_encoder_for(model, amp_dtype) or None
+    cache = model.__dict__.setdefault("_ts_lean_classifiers", {})
+    if amp_dtype not in cache:
+        try:
+            cache[amp_dtype] = LeanBertClassifier(model, amp_dtype)
+        except Exception:
+            cache[amp_dtype] = False
+    return cache[amp_dtype] or None
+
+
 class GraphedForward:
     """Batch-1 encoder forwards replayed from captured HIP graphs.
 
@@ -221,6 +251,7 @@ class GraphedForward:
         self.model = model
         self.pad = int(pad_token_id or 0)
         self.amp_dtype = amp_dtype
+        self.lean_forward = True      # capture the written-out forward (LeanBertEncoder / LeanModernBertEncoder) when there is one
         self._graphs: Dict[int, Tuple[Any, torch.Tensor, torch.Tensor, torch.Tensor]] = {}
         self._broken = False
 
@@ -230,6 +261,9 @@ class GraphedForward:
         # cached would keep reading that freed memory on every replay, so the forward runs
         # outside any caller context and with the cache off (the casts become graph nodes).
         with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            lean = _lean_for_graph(self.model, self.amp_dtype, False) if self.lean_forward else None
+            if lean is not None:    # (the padded bucket's mask is a prefix mask by construction: no look at it on the host)
+                return lean(ids, mask, None, lengths=mask.sum(1, dtype=torch.int32))
             if self.amp_dtype is not None:
                 with torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False):
                     return self.model(input_ids=ids, attention_mask=mask).last_hidden_state
@@ -287,6 +321,7 @@ class GraphedClassifier:
         self.pad = int(pad_token_id or 0)
         self.amp_dtype = amp_dtype
         self.use_token_types = use_token_types
+        self.lean_forward = True
         self._graphs: Dict[Tuple[int, int], Any] = {}
         self._broken = False
 
@@ -295,6 +330,9 @@ class GraphedClassifier:
         if types is not None:
             kw["token_type_ids"] = types
         with torch.no_grad(), torch.autocast("cuda", enabled=False):   # see GraphedForward._run
+            lean = _lean_for_graph(self.model, self.amp_dtype, True) if self.lean_forward else None
+            if lean is not None:
+                return lean(ids, mask, types, lengths=mask.sum(1, dtype=torch.int32)).reshape(ids.shape[0], -1)
             if self.amp_dtype is not None:
                 with torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False):
                     return self.model(**kw).logits.float()
@@ -429,6 +467,7 @@ class SentenceEncoder:
             idx = order[s:s + batch_size]
             enc = self.tokenizer([texts[i] for i in idx], truncation=True, padding=True,
                                  max_length=self.max_seq_length, return_tensors="pt")
+            lengths = _prefix_lengths(enc, self.tokenizer)
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
                 enc.pop("token_type_ids")
@@ -442,7 +481,8 @@ class SentenceEncoder:
                 lean = False
                 if self.lean_forward and str(self.device).startswith("cuda") and torch.is_autocast_enabled("cuda"):
                     lean = lean_encoder_for(self.model, torch.get_autocast_dtype("cuda"))
-                hidden = (lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids")) if lean
+                hidden = (lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"),
+                               lengths=lengths.to(self.device) if lengths is not None else None) if lean
                           else self.model(**enc).last_hidden_state)
             emb = self._pool(hidden.float(), enc["attention_mask"])
             for d in self.dense:
@@ -1008,9 +1048,11 @@ class CrossEncoderModel:
             idx = order[s:s + batch_size]
             enc = self.tokenizer([pairs[i][0] for i in idx], [pairs[i][1] for i in idx], truncation=True,
                                  padding=True, max_length=self.max_length, return_tensors="pt")
+            lengths = _prefix_lengths(enc, self.tokenizer)
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
-            with _autocast(self.device, self.use_amp, self.amp_dtype):
-                lg = self.model(**enc).logits.float()
+            if lengths is not None:
+                enc["lengths"] = lengths.to(self.device)
+            lg = self.logits_from_ids(enc)        # the written-out forward when there is one, else the module under AMP
             res[torch.as_tensor(np.ascontiguousarray(idx), device=self.device)] = lg.reshape(len(idx), -1)
         return res
 

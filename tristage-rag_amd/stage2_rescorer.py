@@ -153,13 +153,15 @@ class ColBERTScorer:
         return out
 
     def _forward(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
+        lengths = enc.get("lengths")
+        enc = {k: v for k, v in enc.items() if k != "lengths"}
         with torch.no_grad():
             if self.use_amp:
                 if getattr(self, "lean_forward", True):
-                    from .encoders import lean_encoder_for   # BERT-family token encoders: the written-out forward
+                    from .encoders import lean_encoder_for   # BERT-family / ModernBERT token encoders: the written-out forward
                     lean = lean_encoder_for(self.model, torch.bfloat16)
                     if lean:
-                        return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"))
+                        return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"), lengths=lengths)
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     return self.model(**enc).last_hidden_state
             return self.model(**enc).last_hidden_state
@@ -169,7 +171,12 @@ class ColBERTScorer:
         texts = [t if t and t.strip() else "empty" for t in texts]
         enc = self.tokenizer(texts, truncation=True, padding=True, max_length=self.config.max_seq_length,
                              return_tensors="pt")
-        return self._model_inputs(enc)
+        from .encoders import _prefix_lengths
+        lengths = _prefix_lengths(enc, self.tokenizer)      # on the host: the written-out forward then needs no mask check
+        out = self._model_inputs(enc)
+        if lengths is not None:
+            out["lengths"] = lengths.to(self.device)
+        return out
 
     def _pool_embeddings(self, embeddings: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """reference :115-132 (not used by the scoring path; kept for API parity)"""
