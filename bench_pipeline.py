@@ -108,7 +108,8 @@ def main():
                    "queries_per_search_many": args.many, "bm25_rrf": args.bm25,
                    "stage3_token_id_cache": args.ids, "stage3_pairs_per_forward": args.s3_batch,
                    "stage3_lean_forward": bool(getattr(p.stage3.model, "_lean", None)), "save_intermediate_results": args.keep,
-                   "array_path": bool(args.ids and args.store and args.many and getattr(p.stage3, "_pairs_usable", False))},
+                   "array_path": bool(args.ids and args.store and getattr(p.stage3, "_pairs_usable", False)
+                                      and (args.many or p.config.search_on_arrays))},
         "index_build_s": round(t_index, 3),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,

@@ -603,6 +603,17 @@ def test_search_many_on_arrays_equals_the_record_path(encoder, tmp_path, bm25, f
     for x, y in zip(lean, ra):
         assert x["stage1_results"] == [] and x["stage2_results"] == []
         assert [r["doc_id"] for r in x["results"]] == [r["doc_id"] for r in y["results"]]
+    # search() takes the same path for one query; search_on_arrays=False restores the per-record path
+    took.clear()
+    one = a.search(qs[1], top_k=5)
+    assert took == [1] and set(one) == set(ra[1])
+    a.config.search_on_arrays = False
+    rec = a.search(qs[1], top_k=5)
+    assert took == [1]
+    assert [r["doc_id"] for r in one["results"]] == [r["doc_id"] for r in rec["results"]] == [r["doc_id"] for r in ra[1]["results"]]
+    for u, v in zip(one["results"], rec["results"]):
+        assert u["stage3_score"] == pytest.approx(v["stage3_score"], abs=1e-5) and u["stage2_score"] == pytest.approx(v["stage2_score"], abs=1e-5)
+    a.config.search_on_arrays = True
     # fewer documents than stage1_top_k: the record path (padded results) takes over
     small = cpu_pipeline(tmp_path, name="s", stage3_cache_document_tokens=True, **kw)
     small.add_documents(docs[:30])

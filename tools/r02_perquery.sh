@@ -6,8 +6,7 @@ timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/gpu_full.log 2>&1; t
 timeout -k 10 300 python bench_pipeline.py --queries 64 --store 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
 timeout -k 10 300 python bench_pipeline.py --queries 64 --store --graphs 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
 timeout -k 10 300 python bench_pipeline.py --queries 64 --store --ids 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
-timeout -k 10 300 python bench_pipeline.py --queries 256 --store --many 64 --ids 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
-timeout -k 10 300 python bench_pipeline.py --queries 256 --store --many 64 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
+timeout -k 10 300 python bench_pipeline.py --queries 64 --store --ids --graphs 2>>$O/err.log | tail -1 >> $O/pipeline.jsonl
 python - <<'PY'
 import json
 for l in open("gpurun_out/r02d/pipeline.jsonl"):

@@ -1036,12 +1036,7 @@ class CrossEncoderModel:
             enc = self.tokenizer([p[0] for p in pairs], [p[1] for p in pairs], truncation=True, padding=True,
                                  max_length=self.max_length, return_tensors="pt")
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
-            if self._graphed is None:
-                self._graphed = GraphedClassifier(self.model, getattr(self.tokenizer, "pad_token_id", 0) or 0,
-                                                  self.amp_dtype if self.use_amp else None,
-                                                  use_token_types="token_type_ids" in enc and
-                                                  hasattr(self.model.config, "type_vocab_size"))
-            lg = self._graphed(enc)
+            lg = self.logits_graphed(enc)
             if lg is not None:
                 return lg.reshape(len(pairs), -1)
         for s in range(0, len(pairs), batch_size):
@@ -1055,6 +1050,19 @@ class CrossEncoderModel:
             lg = self.logits_from_ids(enc)        # the written-out forward when there is one, else the module under AMP
             res[torch.as_tensor(np.ascontiguousarray(idx), device=self.device)] = lg.reshape(len(idx), -1)
         return res
+
+    def logits_graphed(self, enc: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
+        """Logits [P, num_labels] of one query's assembled pairs from a replayed HIP graph, or None (graphs off, no
+        bucket for the shape, capture failed: the caller runs the eager forward)."""
+        if not (self.use_hip_graph and str(self.device).startswith("cuda")) or enc["input_ids"].shape[0] > GraphedClassifier.ROWS[-1]:
+            return None
+        if self._graphed is None:
+            self._graphed = GraphedClassifier(self.model, getattr(self.tokenizer, "pad_token_id", 0) or 0,
+                                              self.amp_dtype if self.use_amp else None,
+                                              use_token_types="token_type_ids" in enc and
+                                              hasattr(self.model.config, "type_vocab_size"))
+        lg = self._graphed(enc)
+        return lg.reshape(enc["input_ids"].shape[0], -1) if lg is not None else None
 
     def activate(self, lg: torch.Tensor) -> torch.Tensor:
         if self.activation == "sigmoid":

@@ -70,6 +70,7 @@ class PipelineConfig:
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
     stage2_token_store_dtype: str = "auto"   # "auto": bf16 under AMP, else the encoder's output type; or bf16 | f16 | f32
+    search_on_arrays: bool = True               # search() takes the array path of search_many when its preconditions hold
     stage3_cache_document_tokens: bool = False  # tokenise every document once at add time; search_many then assembles
                                                 # the cross-encoder inputs from token ids on the GPU
     stage3_many_batch_size: int = 1024       # pairs per cross-encoder forward in search_many
@@ -242,6 +243,12 @@ class RetrievalPipeline:
         if not self.stage1 or not self.stage2 or not self.stage3:
             self.initialize_stages()
         top_k = top_k or self.config.stage3_top_k
+        if self.config.search_on_arrays:
+            # one query through the array path of search_many (resident token store + stage-3 id cache): no candidate
+            # text is tokenised or re-encoded, one cross-encoder forward for the query's pairs; same records (tests)
+            fast = self._search_many_arrays([query], top_k)
+            if fast is not None:
+                return fast[0]
         total_start = self._now()
         try:
             t = self._now()

@@ -368,6 +368,8 @@ class ColBERTScorer:
         """Token matrices [Lq_j, H] of several queries from ONE padded forward (the reference
         encodes one query per call, :203-205; same values up to batch-padding noise)."""
         out: List[torch.Tensor] = []
+        if len(queries) == 1 and self.config.use_hip_graph and str(self.device).startswith("cuda"):
+            return [self._encode_single_text(queries[0])[0]]       # one query: the graph-replayed batch-1 forward
         bs = max(self.config.batch_size, 1)
         for s in range(0, len(queries), bs):
             enc = self._tokenize_batch(list(queries[s:s + bs]))

@@ -221,7 +221,8 @@ class CrossEncoderReranker:
         for j, s in enumerate(range(0, B * C, bs)):
             sel = order[s: s + bs]
             enc = pa.batch(plan, sel, width=int(widths[j]))
-            raw[sel] = self.model.activate(self.model.logits_from_ids(enc)).reshape(-1)
+            lg = self.model.logits_graphed(enc) if B * C <= bs else None   # one query's pairs: graph replay if enabled
+            raw[sel] = self.model.activate(lg if lg is not None else self.model.logits_from_ids(enc)).reshape(-1)
         a = raw.view(B, C).to(torch.float64)
         if self.config.normalize_scores:
             mn, mx = a.min(dim=1, keepdim=True).values, a.max(dim=1, keepdim=True).values
