@@ -681,6 +681,8 @@ def test_lean_encoder_forward_equals_the_transformers_module(spec):
     assert got16.dtype == torch.float32 and float((got16[valid] - ref16[valid]).abs().max()) < 0.05 * float(ref16.abs().max())
     assert lean_encoder_for(model, torch.bfloat16) is lean_encoder_for(model, torch.bfloat16)      # built once per dtype
     assert lean_encoder_for(torch.nn.Linear(2, 2), torch.bfloat16) is False                         # no such architecture
+    with pytest.raises(ValueError):                                                                 # beyond the position table
+        LeanBertEncoder(model, None)(torch.zeros((1, 600), dtype=torch.long), None)
     enc = SentenceEncoder(spec, device="cpu")
     with torch.autocast("cpu", dtype=torch.bfloat16):
         enc.encode(["a b c", "d"])

@@ -271,6 +271,10 @@ def test_fused_add_layernorm_matches_torch(xdt, H, rows):
             assert torch.equal(ylp, y32.to(lp))                   # the 16-bit copy is the rounded fp32 result
     only32, none_lp = add_layernorm(x, res, gamma, beta, 1e-5, lp_dtype=None)
     assert none_lp is None and only32 is not None
+    with pytest.raises(ValueError):                                # parameter vectors of another width
+        add_layernorm(x, res, gamma[:-4], beta, 1e-5, lp_dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        add_layernorm(x, res.half(), gamma, beta, 1e-5, lp_dtype=torch.bfloat16)
     # 3-D input, as the encoder passes it
     y32, ylp = add_layernorm(x.view(1, rows, H), res.view(1, rows, H), gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
     assert y32.shape == (1, rows, H)
@@ -355,6 +359,8 @@ def test_fused_embed_layernorm_matches_torch(H, V, shape, types):
         embed_layernorm(ids, pid, tt, word.half(), pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         embed_layernorm(ids, pid[:, :-1], tt, word, pos, typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        embed_layernorm(ids, pid, tt, word, pos[:, :-4].contiguous(), typ, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)
 
 
 def test_stage1_and_stage2_encoders_use_the_written_out_forward_under_amp():

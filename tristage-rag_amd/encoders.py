@@ -785,6 +785,8 @@ class LeanBertEncoder:
         else:   # RoBERTa family: positions count the non-padding tokens, offset by the padding index
             nonpad = (input_ids != self.pad_idx).to(torch.int64)
             pos = torch.cumsum(nonpad, dim=1) * nonpad + self.pad_idx
+        if L + (0 if self.kind == "bert" else self.pad_idx + 1) > int(self.pos.shape[0]):
+            raise ValueError(f"sequence length {L} exceeds the model's {int(self.pos.shape[0])} position embeddings")
         H, nh = int(self.word.shape[-1]), self.heads
         fused = (self.fused_layernorm and self.cd in (torch.bfloat16, torch.float16) and input_ids.is_cuda and H % 4 == 0 and H <= 2048)
         if fused:

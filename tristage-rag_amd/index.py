@@ -446,6 +446,9 @@ def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32:
             raise ValueError("residual must be float32 with x's shape")
     gamma = gamma.detach().contiguous()
     beta = beta.detach().contiguous() if beta is not None else None
+    for t in (gamma, beta):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != H or t.device != x.device):
+            raise ValueError("gamma / beta must be float32 [H] on x's device")
     out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
     outlp = torch.empty(x.shape, dtype=lp_dtype, device=x.device) if lp_dtype is not None else None
     dev = x.device.index
@@ -517,9 +520,11 @@ def embed_layernorm(ids, pos_ids, type_ids, word, pos, typ, gamma, beta, eps: fl
     torch = _torch()
     lib = _lib.load()
     H = int(word.shape[-1])
-    tabs = [t.detach() for t in (word, pos, typ, gamma, beta)]
-    if any(t.dtype != torch.float32 or not t.is_contiguous() or t.device != ids.device for t in tabs):
+    tabs = [t.detach() if t is not None else None for t in (word, pos, typ, gamma, beta)]
+    if any(t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != ids.device) for t in tabs):
         raise ValueError("embedding tables and LayerNorm parameters must be contiguous float32 on the ids' device")
+    if any(t.dim() != 2 or t.shape[-1] != H for t in tabs[:3]) or tabs[3].numel() != H or (tabs[4] is not None and tabs[4].numel() != H):
+        raise ValueError("embedding tables must be [*, H] and gamma / beta [H]")
     idx = [ids.contiguous(), pos_ids.contiguous(), type_ids.contiguous() if type_ids is not None else None]
     if any(t is not None and (t.dtype != torch.int64 or t.shape != ids.shape) for t in idx):
         raise ValueError("ids, pos_ids and type_ids must be int64 of one shape")
