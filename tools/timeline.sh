@@ -9,7 +9,9 @@ f=glob.glob("$OUT/t/*/*_kernel_trace.csv")[0]
 rows=[r for r in csv.DictReader(open(f))]
 ks=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"][:40]) for r in rows]
 ks.sort()
-scan=[k for k in ks if "scan_kernel<1, 2, 1>" in k[2]]
+import os
+pat=os.environ.get("TL_KERNEL","scan_kernel<1, 2, 1>")
+scan=[k for k in ks if pat in k[2]]
 last=scan[-30:]
 t0=last[0][0]
 gaps=[(b[0]-a[1])/1e3 for a,b in zip(last,last[1:])]
