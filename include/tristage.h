@@ -228,6 +228,13 @@ int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, const int64
                       const double* len_norm, double k1p1);
 int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
                    double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream);
+/* The same for nq queries with ONE synchronisation: query q's terms are
+ * term_ids[term_off[q] .. term_off[q+1]) (host arrays; term_off has nq+1 entries), its
+ * results out_scores / out_ids [q*k .. q*k + n_out[q]).  Each query is scored exactly as by
+ * ts_bm25_search (same kernels, same order of additions), one after the other on `stream`. */
+int ts_bm25_search_batch(ts_bm25* h, const int32_t* term_ids, const int64_t* term_off, int32_t nq,
+                         int32_t k, double* out_scores, int64_t* out_ids, int32_t* n_out,
+                         void* stream);
 
 /* ---- fused residual add + LayerNorm (between the GEMMs of the encoder forwards) ---
  * The cross-encoder forward the reference reaches through CrossEncoder.predict

@@ -48,6 +48,35 @@ def test_gpu_bm25_equals_host_bm25_on_a_larger_corpus():
     gpu.close()
 
 
+def test_gpu_bm25_batch_equals_single_queries():
+    """BM25Index.search_many (ts_bm25_search_batch: one call, one synchronisation) == search() per query, bit for
+    bit, including queries without a known term, repeated queries, and a batch after a batch (state left clean)."""
+    from tristage_rag_amd.stage1_retriever import BM25Index
+    rng = np.random.default_rng(9)
+    vocab = [f"w{i}" for i in range(300)]
+    p = 1.0 / np.arange(1, 301)
+    p /= p.sum()
+    docs = [" ".join(rng.choice(vocab, size=int(rng.integers(3, 50)), p=p)) for _ in range(30_000)]
+    host, gpu = BM25Index(), BM25Index(gpu_device=0)
+    host.fit(docs)
+    gpu.fit(docs)
+    queries = ["w0 w1 w2", "zzz", "w299", "", "w0", "w5 w5 w17 nosuch", "w0 w1 w2"] + \
+              [" ".join(rng.choice(vocab, size=int(rng.integers(1, 9)))) for _ in range(57)]
+    for k in (10, 300):
+        for _ in range(2):
+            many = gpu.search_many(queries, k)
+            assert len(many) == len(queries)
+            for q, got in zip(queries, many):
+                assert got == gpu.search(q, k) == host.search(q, k)
+            for (ai, asc), got in zip(gpu.search_many_arrays(queries, k), many):      # the array form: same lists
+                assert ai.dtype == np.int64 and asc.dtype == np.float64
+                assert list(zip(ai.tolist(), asc.tolist())) == got
+    for (ai, asc), q in zip(host.search_many_arrays(queries[:5], 7), queries[:5]):
+        assert list(zip(ai.tolist(), asc.tolist())) == host.search(q, 7)
+    assert gpu.search_many([], 5) == [] and host.search_many(queries[:3], 5) == [host.search(q, 5) for q in queries[:3]]
+    gpu.close()
+
+
 def test_gpu_bm25_prefilter_and_its_fallbacks():
     """Long touched lists go through the sampled threshold + chip-wide filter before the exact
     select; massive ties overflow the candidate list and must fall back to the exact select over

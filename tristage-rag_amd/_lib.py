@@ -57,6 +57,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, ctypes.c_double]),
     "ts_bm25_search": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                  POINTER(c_int32), c_void_p]),
+    "ts_bm25_search_batch": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "ts_add_layernorm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p,
                                    c_void_p, c_int32, c_int32, c_void_p]),
     "ts_embed_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,

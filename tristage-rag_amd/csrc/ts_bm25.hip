@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <new>
+#include <vector>
 
 #define BM_SEL_THREADS 1024
 #define BM_MAX_K 2048
@@ -51,6 +52,8 @@ struct ts_bm25 {
   int32_t* out_i = nullptr;    // [BM_MAX_K]
   int64_t* term_off = nullptr;  // host copy [V+1]
   double* idf_host = nullptr;
+  void* batch_buf = nullptr;   // results of a query batch (device), grown on demand
+  size_t batch_bytes = 0;
 };
 
 namespace {
@@ -302,9 +305,10 @@ extern "C" int ts_bm25_create(int32_t device, ts_bm25** out) {
 
 static void bm25_free(ts_bm25* h) {
   void* bufs[] = {h->post_doc, h->post_tf, h->idf, h->len_norm, h->acc, h->touched, h->counters, h->out_s, h->out_i,
-                  h->keys, h->cand, h->tau};
+                  h->keys, h->cand, h->tau, h->batch_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  h->batch_buf = nullptr; h->batch_bytes = 0;
   h->post_doc = nullptr; h->post_tf = nullptr; h->idf = nullptr; h->len_norm = nullptr; h->acc = nullptr;
   h->touched = nullptr; h->counters = nullptr; h->out_s = nullptr; h->out_i = nullptr;
   h->keys = nullptr; h->cand = nullptr; h->tau = nullptr;
@@ -364,17 +368,10 @@ extern "C" int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, 
 // term_ids: the query's tokens mapped to vocabulary ids, in query order (unknown
 // tokens dropped, repeats kept).  Writes up to k (score, doc) pairs, best first;
 // *n_out < k means every document with a non-zero score is in the output.
-extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
-                              double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream) {
-  if (!h || !out_scores || !out_ids || !n_out || n_terms < 0 || k <= 0 || (n_terms && !term_ids)) {
-    ts_set_error("bad arguments to bm25_search");
-    return TS_ERR_INVALID;
-  }
-  if (k > BM_MAX_K) { ts_set_error("bm25 top_k %d exceeds %d", k, BM_MAX_K); return TS_ERR_UNSUPPORTED; }
-  *n_out = 0;
-  if (h->N == 0 || n_terms == 0) return TS_OK;
-  Guard g(h->device);
-  hipStream_t s = (hipStream_t)stream;
+// One query's launches; results land in out_s / out_i (device, k entries) and its count in *cnt_out (device); the
+// accumulator, the touched list and the counters are back to zero afterwards.  Everything is stream-ordered.
+static int bm25_enqueue_query(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k, double* out_s,
+                              int32_t* out_i, uint32_t* cnt_out, hipStream_t s) {
   int64_t total_df = 0;
   for (int i = 0; i < n_terms; ++i) {
     const int32_t t = term_ids[i];
@@ -394,22 +391,79 @@ extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_ter
     hipLaunchKernelGGL(bm25_filter, dim3(blocks), dim3(256), 0, s, h->touched, h->counters, h->keys, h->tau,
                        h->cand, h->counters);
     hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->cand, h->counters + 2, h->acc, k,
-                       h->out_s, h->out_i, h->counters + 1, h->counters, 1);
+                       out_s, out_i, h->counters + 1, h->counters, 1);
   }
   // (runs only when the candidate list was not made or is not usable)
   hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->touched, h->counters, h->acc, k,
-                     h->out_s, h->out_i, h->counters + 1, h->counters, 0);
+                     out_s, out_i, h->counters + 1, h->counters, 0);
   TS_HIP(hipGetLastError());
-  uint32_t cnt[2] = {0, 0};
-  static thread_local int32_t ids32[BM_MAX_K];
-  TS_HIP(hipMemcpyAsync(cnt, h->counters, 8, hipMemcpyDeviceToHost, s));
-  TS_HIP(hipMemcpyAsync(out_scores, h->out_s, (size_t)k * 8, hipMemcpyDeviceToHost, s));
-  TS_HIP(hipMemcpyAsync(ids32, h->out_i, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipMemcpyAsync(cnt_out, h->counters + 1, 4, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
   TS_HIP(hipMemsetAsync(h->counters, 0, 16, s));
-  TS_HIP(hipStreamSynchronize(s));
-  const int32_t n = (int32_t)cnt[1];
-  for (int32_t i = 0; i < n; ++i) out_ids[i] = ids32[i];
-  *n_out = n;
   return TS_OK;
+}
+
+extern "C" int ts_bm25_search_batch(ts_bm25* h, const int32_t* term_ids, const int64_t* term_off, int32_t nq, int32_t k,
+                                    double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream) {
+  if (!h || !out_scores || !out_ids || !n_out || !term_off || nq < 0 || k <= 0) {
+    ts_set_error("bad arguments to bm25_search_batch");
+    return TS_ERR_INVALID;
+  }
+  if (k > BM_MAX_K) { ts_set_error("bm25 top_k %d exceeds %d", k, BM_MAX_K); return TS_ERR_UNSUPPORTED; }
+  for (int q = 0; q < nq; ++q) {
+    n_out[q] = 0;
+    if (term_off[q + 1] < term_off[q] || (term_off[q + 1] > term_off[q] && !term_ids)) {
+      ts_set_error("bad term offsets in bm25_search_batch");
+      return TS_ERR_INVALID;
+    }
+  }
+  if (nq == 0 || h->N == 0) return TS_OK;
+  Guard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  // per-batch result buffers (device): [nq, k] scores, [nq, k] ids, [nq] counts — one copy back and ONE sync per batch
+  const size_t need = (size_t)nq * k * 12 + (size_t)nq * 4;
+  if (need > h->batch_bytes) {
+    if (h->batch_buf) (void)hipFree(h->batch_buf);
+    h->batch_buf = nullptr; h->batch_bytes = 0;
+    TS_HIP(hipMalloc(&h->batch_buf, need));
+    h->batch_bytes = need;
+  }
+  double* bs = reinterpret_cast<double*>(h->batch_buf);
+  int32_t* bi = reinterpret_cast<int32_t*>(bs + (size_t)nq * k);
+  uint32_t* bc = reinterpret_cast<uint32_t*>(bi + (size_t)nq * k);
+  TS_HIP(hipMemsetAsync(bc, 0, (size_t)nq * 4, s));
+  int st = TS_OK;
+  for (int q = 0; q < nq && st == TS_OK; ++q) {
+    const int64_t nt = term_off[q + 1] - term_off[q];
+    if (nt == 0) continue;
+    st = bm25_enqueue_query(h, term_ids + term_off[q], (int32_t)nt, k, bs + (size_t)q * k, bi + (size_t)q * k, bc + q, s);
+  }
+  if (st != TS_OK) {   // a bad term id part-way: leave the handle clean (accumulator / counters) before reporting it
+    hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
+    (void)hipMemsetAsync(h->counters, 0, 16, s);
+    (void)hipStreamSynchronize(s);
+    return st;
+  }
+  std::vector<int32_t> ids32((size_t)nq * k);
+  std::vector<uint32_t> cnt((size_t)nq);
+  TS_HIP(hipMemcpyAsync(out_scores, bs, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipMemcpyAsync(ids32.data(), bi, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipMemcpyAsync(cnt.data(), bc, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  TS_HIP(hipStreamSynchronize(s));
+  for (int q = 0; q < nq; ++q) {
+    const int32_t n = (int32_t)std::min<uint32_t>(cnt[q], (uint32_t)k);
+    for (int32_t i = 0; i < n; ++i) out_ids[(size_t)q * k + i] = ids32[(size_t)q * k + i];
+    n_out[q] = n;
+  }
+  return TS_OK;
+}
+
+extern "C" int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k,
+                              double* out_scores, int64_t* out_ids, int32_t* n_out, void* stream) {
+  if (!h || !out_scores || !out_ids || !n_out || n_terms < 0 || k <= 0 || (n_terms && !term_ids)) {
+    ts_set_error("bad arguments to bm25_search");
+    return TS_ERR_INVALID;
+  }
+  const int64_t off[2] = {0, n_terms};
+  return ts_bm25_search_batch(h, term_ids, off, 1, k, out_scores, out_ids, n_out, stream);
 }

@@ -674,6 +674,17 @@ class PairAssembler:
             self._table = (str(device), torch.from_numpy(ids).to(device), torch.from_numpy(lens).to(device))
         return self._table[1], self._table[2]
 
+    def _device_consts(self, device):
+        """The template's special-token runs as device tensors, uploaded once per device: a host-to-device copy inside
+        batch() would be a host sync per cross-encoder forward (the GPU then idles while the next forward is enqueued)."""
+        cache = self.__dict__.setdefault("_consts", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = {tuple(v): torch.as_tensor(list(v), dtype=torch.int64, device=device)
+                          for v in (self.prefix, self.middle, self.suffix) if v}
+            cache[key][()] = torch.zeros((1, 1), dtype=torch.int64, device=device)
+        return cache[key]
+
     # -- batch tensors -----------------------------------------------------------------
     def plan(self, q_ids: List[List[int]], pair_q, pair_slot, device):
         """Everything that does not depend on the batch cut: per-pair kept lengths and total length.
@@ -708,11 +719,12 @@ class PairAssembler:
         qpart = torch.gather(qrows, 1, (t - a0).clamp(0, qrows.shape[1] - 1).expand(len(sel), L))
         dpart = torch.gather(drows, 1, (t - a2).clamp(0, drows.shape[1] - 1).expand(len(sel), L))
 
+        consts = self._device_consts(dev)
+
         def const(vals, off):   # special tokens at positions off + i
             if not vals:
-                return torch.zeros((1, 1), dtype=torch.int64, device=dev)
-            v = torch.as_tensor(vals, dtype=torch.int64, device=dev)
-            return v[(t - off).clamp(0, len(vals) - 1)]
+                return consts[()]
+            return consts[tuple(vals)][(t - off).clamp(0, len(vals) - 1)]
         ids = torch.full((len(sel), L), self.pad, dtype=torch.int64, device=dev)
         ids = torch.where(t < a4, const(self.suffix, a3), ids)
         ids = torch.where(t < a3, dpart, ids)

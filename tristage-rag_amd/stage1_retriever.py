@@ -141,18 +141,39 @@ class BM25Index:
                                          idf.ctypes.data, ln.ctypes.data, float(self.k1 + 1)))
 
     def _search_gpu(self, query: str, top_k: int) -> List[Tuple[int, float]]:
-        import ctypes
+        return self._search_gpu_many([query], top_k)[0]
+
+    def _search_gpu_many(self, queries: Sequence[str], top_k: int, arrays: bool = False):
+        """All queries through ts_bm25_search_batch: one call and one synchronisation for the batch."""
         from . import _lib
         lib = _lib.load()
-        ids = np.array([self._term_id[t] for t in self.tokenize(query) if t in self._term_id], dtype=np.int32)
+        terms = [np.array([self._term_id[t] for t in self.tokenize(q) if t in self._term_id], dtype=np.int32) for q in queries]
+        off = np.zeros(len(queries) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(t) for t in terms])
+        flat = np.concatenate(terms) if len(terms) and off[-1] else np.zeros(1, dtype=np.int32)
         k = min(int(top_k), max(self.corpus_size, 1))
-        out_s = np.zeros(max(k, 1), dtype=np.float64)
-        out_i = np.zeros(max(k, 1), dtype=np.int64)
-        n = ctypes.c_int32(0)
-        if k > 0 and len(ids):
-            _lib.check(lib.ts_bm25_search(self._gpu, ids.ctypes.data, len(ids), k, out_s.ctypes.data,
-                                          out_i.ctypes.data, ctypes.byref(n), None))
-        res = [(int(out_i[i]), float(out_s[i])) for i in range(n.value)]
+        nq = len(queries)
+        out_s = np.zeros((nq, max(k, 1)), dtype=np.float64)
+        out_i = np.zeros((nq, max(k, 1)), dtype=np.int64)
+        n_out = np.zeros(max(nq, 1), dtype=np.int32)
+        if k > 0 and nq and off[-1]:
+            _lib.check(lib.ts_bm25_search_batch(self._gpu, flat.ctypes.data, off.ctypes.data, nq, k, out_s.ctypes.data,
+                                                out_i.ctypes.data, n_out.ctypes.data, None))
+        if arrays:      # (ids, scores) per query, no tuples: the array path of Stage1Retriever fuses them as they are
+            want = min(int(top_k), self.corpus_size)
+            out = []
+            for q in range(nq):
+                n = int(n_out[q])
+                if n < want:    # documents without a query term score exactly 0.0 and follow in ascending id order
+                    pad = self._pad_with_zero_scores(list(zip(out_i[q, :n].tolist(), out_s[q, :n].tolist())), top_k)
+                    out.append((np.array([i for i, _ in pad], dtype=np.int64), np.array([v for _, v in pad], dtype=np.float64)))
+                else:
+                    out.append((out_i[q, :n], out_s[q, :n]))
+            return out
+        return [self._pad_with_zero_scores(list(zip(out_i[q, : n_out[q]].tolist(), out_s[q, : n_out[q]].tolist())), top_k)
+                for q in range(nq)]
+
+    def _pad_with_zero_scores(self, res: List[Tuple[int, float]], top_k: int) -> List[Tuple[int, float]]:
         if len(res) < min(top_k, self.corpus_size):
             # every document with a non-zero score is listed; the rest score exactly 0.0 and
             # follow in ascending id order (the reference's stable sort)
@@ -198,6 +219,23 @@ class BM25Index:
             ds, tf = p
             acc[ds] += self.idf[tok] * ((tf * (self.k1 + 1)) / (tf + self._len_norm[ds]))
         return acc
+
+    def search_many(self, queries: Sequence[str], top_k: int = 10) -> List[List[Tuple[int, float]]]:
+        """search() for several queries (the GPU index takes them in one call)."""
+        if self._gpu is not None:
+            return self._search_gpu_many(list(queries), top_k)
+        return [self.search(q, top_k) for q in queries]
+
+    def search_many_arrays(self, queries: Sequence[str], top_k: int = 10):
+        """search_many() as (ids int64 [n], scores float64 [n]) per query."""
+        if self._gpu is not None:
+            return self._search_gpu_many(list(queries), top_k, arrays=True)
+        out = []
+        for q in queries:
+            r = self.search(q, top_k)
+            out.append((np.fromiter((i for i, _ in r), dtype=np.int64, count=len(r)),
+                        np.fromiter((v for _, v in r), dtype=np.float64, count=len(r))))
+        return out
 
     def search(self, query: str, top_k: int = 10) -> List[Tuple[int, float]]:
         if self._gpu is not None:
@@ -430,8 +468,10 @@ class Stage1Retriever:
         ids, scores = I.cpu().numpy(), D.cpu().numpy()
         out_i = np.empty((len(queries), top_k), dtype=np.int64)
         out_s = np.empty((len(queries), top_k), dtype=np.float64)
-        for qi, query in enumerate(queries):
-            bm = self.bm25_index.search(query, self.config.bm25_top_k)
+        bm25 = self.bm25_index
+        bms = (bm25.search_many_arrays(list(queries), self.config.bm25_top_k) if hasattr(bm25, "search_many_arrays")
+               else [bm25.search(q, self.config.bm25_top_k) for q in queries])
+        for qi, bm in enumerate(bms):
             fi, fs = self._fuse_arrays(ids[qi], scores[qi], bm)
             if len(fi) < top_k:
                 return None
@@ -442,10 +482,15 @@ class Stage1Retriever:
         """The fusion of _finish() on arrays: same float64 arithmetic, same order (descending fused score,
         ties in first-seen order: dense list first, then the BM25-only documents) as the dictionary code of
         _reciprocal_rank_fusion / _weighted_fusion (reference :326-366)."""
-        if not bm25_results:
-            return dense_ids, dense_scores.astype(np.float64)
-        b_ids = np.fromiter((i for i, _ in bm25_results), dtype=np.int64, count=len(bm25_results))
-        b_sc = np.fromiter((s for _, s in bm25_results), dtype=np.float64, count=len(bm25_results))
+        if isinstance(bm25_results, tuple):          # (ids, scores) arrays
+            b_ids, b_sc = bm25_results
+            if not len(b_ids):
+                return dense_ids, dense_scores.astype(np.float64)
+        else:                                         # [(id, score), ...]
+            if not bm25_results:
+                return dense_ids, dense_scores.astype(np.float64)
+            b_ids = np.fromiter((i for i, _ in bm25_results), dtype=np.int64, count=len(bm25_results))
+            b_sc = np.fromiter((s for _, s in bm25_results), dtype=np.float64, count=len(bm25_results))
         if self.config.fusion_method == "rrf":
             d_part = 1.0 / (self.config.rrf_k + np.arange(len(dense_ids), dtype=np.float64) + 1)
             b_part = 1.0 / (self.config.rrf_k + np.arange(len(b_ids), dtype=np.float64) + 1)
