@@ -77,7 +77,7 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         s1.doc_metadata.extend(metadata if metadata is not None else [{}] * n)
         mine = list(documents[lo:hi])
         if s1._device_path():
-            emb = s1._encode_batch_tensor(mine) if mine else None
+            emb = s1._encode_batch_tensor(mine, bulk=True) if mine else None
             d = int(emb.shape[1]) if emb is not None else int(s1.embedding_dim)
             local = None
             normalize = True

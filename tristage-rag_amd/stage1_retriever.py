@@ -41,6 +41,7 @@ class Stage1Config:
     index_dir: str = "./faiss_index"
     top_k_candidates: int = 500
     batch_size: int = 32
+    index_batch_size: int = 256     # additive: documents per encoder forward in add_documents on the device path
     max_text_length: int = 512
     enable_bm25: bool = True
     bm25_top_k: int = 300
@@ -310,12 +311,13 @@ class Stage1Retriever:
         return (dev.startswith("cuda") and self._index_factory is None and
                 getattr(self.model, "encode", None) is not None)
 
-    def _encode_batch_tensor(self, texts: List[str]):
+    def _encode_batch_tensor(self, texts: List[str], bulk: bool = False):
         import torch
         ctx = (torch.autocast("cuda", dtype=torch.bfloat16) if self.config.use_fp16
                else torch.autocast("cuda", enabled=False))
+        bs = max(self.config.batch_size, getattr(self.config, "index_batch_size", 0) or 0) if bulk else self.config.batch_size
         with ctx:
-            emb = self.model.encode(texts, batch_size=self.config.batch_size, convert_to_numpy=False,
+            emb = self.model.encode(texts, batch_size=bs, convert_to_numpy=False,
                                     convert_to_tensor=True, show_progress_bar=False)
         return emb.float()
 
@@ -344,7 +346,7 @@ class Stage1Retriever:
             metadata = [{}] * len(documents)  # one shared dict, as in the reference (:302)
         self.doc_metadata.extend(metadata)
         if self._device_path():
-            emb = self._encode_batch_tensor(list(documents))
+            emb = self._encode_batch_tensor(list(documents), bulk=True)
             if self.faiss_index is None:
                 from .index import FlatIPIndex
                 self.faiss_index = FlatIPIndex(int(emb.shape[1]), dtype=self.config.index_dtype,

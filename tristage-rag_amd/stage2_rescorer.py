@@ -44,6 +44,8 @@ class Stage2Config:
                                                   # encoder runs under AMP (its last LayerNorm hands back fp32 even
                                                   # then), else the encoder's own output type; or "bf16" | "f16" | "f32"
     use_hip_graph: bool = False                   # replay the batch-1 query forward from a HIP graph
+    index_batch_size: int = 256                   # documents per forward when the token store is filled at add time
+                                                  # (batch_size, the reference's 16, keeps 10^5-document adds launch-bound)
 
 
 class TokenStore:
@@ -282,11 +284,14 @@ class ColBERTScorer:
         gets pipeline id first_doc_id + j (the doc_id stage 1 reports).  Same tokenisation, padding
         and forward as encode_documents_batch (reference :207-242); the valid rows of a batch go
         into the store with ONE masked copy (row-major mask order = document order)."""
-        bs = max(self.config.batch_size, 1)
+        bs = max(self.config.batch_size, getattr(self.config, "index_batch_size", 0) or 0, 1)
         dt = self.store_dtype()
-        for s in range(0, len(documents), bs):
-            chunk = documents[s: s + bs]
-            enc = self._tokenize_batch(list(chunk))
+        # length-sorted batches (little padding in the GEMMs); the slot table remembers where each document went
+        order = sorted(range(len(documents)), key=lambda i: -len(documents[i])) if bs > self.config.batch_size \
+            else list(range(len(documents)))
+        for s in range(0, len(order), bs):
+            idx = order[s: s + bs]
+            enc = self._tokenize_batch([documents[i] for i in idx])
             hidden = self._forward(enc)
             mask = enc["attention_mask"].bool()
             rows = hidden[mask]                                  # [sum(lens), H]
@@ -294,8 +299,8 @@ class ColBERTScorer:
                 rows = rows.to(dt)
             base = len(self.token_store)
             self.token_store.append_packed(rows, mask.sum(dim=1).tolist())
-            for j in range(len(chunk)):
-                self._store_slot[first_doc_id + s + j] = base + j
+            for j, i in enumerate(idx):
+                self._store_slot[first_doc_id + i] = base + j
 
     # -- persistence of the token store (additive; the reference has nothing to persist for stage 2)
     def save_token_store(self, path: str) -> bool:
