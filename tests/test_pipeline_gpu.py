@@ -479,3 +479,40 @@ def test_lean_modernbert_on_gpu_matches_module_under_autocast():
     d = s2._forward(holed)
     hv = holed["attention_mask"].bool()
     assert float((c[hv] - d[hv]).abs().max()) / float(d[hv].abs().max()) < 0.04
+
+
+def test_attention_varlen_random_shapes_sweep():
+    """Seeded sweep over small / ragged / edge shapes of ts_attention_varlen (L = 1, 31..33, lengths 0 and L, both head
+    dimensions, windows smaller and larger than L) against the fp32 reference: no launch fails, padded rows untouched,
+    results within three 16-bit steps."""
+    import torch
+    from tristage_rag_amd.index import attention_varlen
+    rng = np.random.default_rng(int(os.environ.get("TS_TEST_SEED", "20240611")))
+    g = torch.Generator(device="cuda").manual_seed(17)
+    shapes = [(1, 1, 1, 32), (2, 31, 2, 64), (3, 32, 1, 32), (3, 33, 3, 64), (5, 65, 2, 32), (2, 575, 1, 64), (1, 1119, 1, 32)]
+    for _ in range(12):
+        shapes.append((int(rng.integers(1, 40)), int(rng.integers(1, 300)), int(rng.integers(1, 5)), int(rng.choice([32, 64]))))
+    for B, L, nh, dh in shapes:
+        for tdt, step in ((torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)):
+            H = nh * dh
+            qkv = torch.randn((B, L, 3 * H), generator=g, device="cuda").to(tdt)
+            lens_h = rng.integers(0, L + 1, size=B)
+            lens_h[0] = L
+            if B > 1:
+                lens_h[1] = 0                                         # an empty sequence: nothing written
+            lens = torch.as_tensor(lens_h, dtype=torch.int32, device="cuda")
+            window = int(rng.choice([0, 0, 1, 7, 64, 5000]))
+            out = torch.full((B, L, H), 3.0, dtype=tdt, device="cuda")
+            attention_varlen(qkv, lens, nh, out=out, window=window)
+            q, k, v = (qkv.view(B, L, 3, nh, dh)[:, :, i].transpose(1, 2).float() for i in range(3))
+            t = torch.arange(L, device="cuda")
+            valid = t[None, :] < lens[:, None]
+            ok = valid[:, None, None, :] & (((t[:, None] - t[None, :]).abs() <= window) if window else torch.ones((L, L), dtype=torch.bool, device="cuda"))[None, None]
+            s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+            s = s.masked_fill(~ok, float("-inf"))
+            want = torch.nan_to_num(torch.softmax(s, -1), nan=0.0) @ v
+            want = want.transpose(1, 2).reshape(B, L, H)
+            if bool(valid.any()):
+                err = float((out.float() - want)[valid].abs().max())
+                assert err <= 3 * step * max(1.0, float(want[valid].abs().max())), (B, L, nh, dh, window, err)
+            assert bool((out[~valid] == 3.0).all()), (B, L, nh, dh)
