@@ -44,8 +44,9 @@ class Stage2Config:
                                                   # encoder runs under AMP (its last LayerNorm hands back fp32 even
                                                   # then), else the encoder's own output type; or "bf16" | "f16" | "f32"
     use_hip_graph: bool = False                   # replay the batch-1 query forward from a HIP graph
-    index_batch_size: int = 256                   # documents per forward when the token store is filled at add time
-                                                  # (batch_size, the reference's 16, keeps 10^5-document adds launch-bound)
+    index_batch_size: int = 256                   # documents per forward wherever MANY documents are encoded: filling the
+                                                  # token store at add time, re-encoding a query's candidates without one
+                                                  # (batch_size, the reference's 16, keeps both launch-bound)
 
 
 class TokenStore:
@@ -228,7 +229,11 @@ class ColBERTScorer:
                     out[i] = hit
                 else:
                     todo.append(i)
-        bs = self.config.batch_size
+        # (the reference encodes candidates 16 at a time, :207-242; on this GPU that is 63 launch-bound forwards for a
+        # query's 1000 candidates: length-sorted batches of index_batch_size instead, same values up to padding noise)
+        bs = max(self.config.batch_size, getattr(self.config, "index_batch_size", 0) or 0, 1)
+        if bs > self.config.batch_size:
+            todo = sorted(todo, key=lambda i: -len(documents[i]))
         for s in range(0, len(todo), bs):
             idx = todo[s:s + bs]
             enc = self._tokenize_batch([documents[i] for i in idx])
