@@ -72,17 +72,20 @@ class HashTokenizer:
         self.model_max_length = int(model_max_length)
         self._memo = {}
 
-    def _ids(self, text: str) -> List[int]:
+    def _ids_np(self, text: str) -> np.ndarray:
         hit = self._memo.get(text)          # the same documents / queries recur across pairs and queries
         if hit is not None:
-            return list(hit)
+            return hit
         pieces = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", text.lower())
         span = self.vocab_size - 1000
-        ids = [1000 + (zlib.crc32(p.encode("utf-8")) % span) for p in pieces]
+        ids = np.fromiter((1000 + (zlib.crc32(p.encode("utf-8")) % span) for p in pieces), dtype=np.int64, count=len(pieces))
         if len(self._memo) >= 100_000:
             self._memo.clear()
-        self._memo[text] = tuple(ids)
+        self._memo[text] = ids
         return ids
+
+    def _ids(self, text: str) -> List[int]:
+        return self._ids_np(text).tolist()
 
     def __call__(self, text, text_pair=None, truncation=True, padding=False, max_length=None,
                  return_tensors=None, **_):
@@ -92,16 +95,16 @@ class HashTokenizer:
         if text_pair is not None:
             pairs = [text_pair] if isinstance(text_pair, str) else list(text_pair)
         max_length = int(max_length or self.model_max_length)
-        rows, types = [], []
+        # per row: (first text ids, second text ids or None) after truncation — arrays, no per-token Python
+        parts = []
         for i, t in enumerate(texts):
-            a = self._ids(t)
+            a = self._ids_np(t)
             if pairs is None:
                 if truncation:
                     a = a[: max(max_length - 2, 0)]
-                ids = [self.cls_token_id] + a + [self.sep_token_id]
-                tt = [0] * len(ids)
+                parts.append((a, None))
             else:
-                b = self._ids(pairs[i])
+                b = self._ids_np(pairs[i])
                 if truncation:  # longest-first truncation, like HF's default strategy: one token at a
                     # time from the longer side, from the pair's second text on ties (closed form)
                     la, lb = len(a), len(b)
@@ -115,23 +118,41 @@ class HashTokenizer:
                             lb, e = lb - c, e - c
                         lb, la = lb - (e + 1) // 2, la - e // 2
                         a, b = a[:max(la, 0)], b[:max(lb, 0)]
-                ids = [self.cls_token_id] + a + [self.sep_token_id] + b + [self.sep_token_id]
-                tt = [0] * (len(a) + 2) + [1] * (len(b) + 1)
-            rows.append(ids)
-            types.append(tt)
-        if padding or return_tensors == "pt":
-            width = max(len(r) for r in rows)
-            if not padding and len({len(r) for r in rows}) > 1:
-                raise ValueError("cannot tensorise ragged rows without padding")
-            mask = [[1] * len(r) + [0] * (width - len(r)) for r in rows]
-            types = [t + [0] * (width - len(t)) for t in types]
-            rows = [r + [self.pad_token_id] * (width - len(r)) for r in rows]
-        else:
-            mask = [[1] * len(r) for r in rows]
-        out = {"input_ids": rows, "attention_mask": mask, "token_type_ids": types}
+                parts.append((a, b))
+        lens = [len(a) + 2 + (len(b) + 1 if b is not None else 0) for a, b in parts]
+        tensorise = padding or return_tensors == "pt"
+        if tensorise and not padding and len(set(lens)) > 1:
+            raise ValueError("cannot tensorise ragged rows without padding")
+        if not tensorise:
+            rows, types = [], []
+            for a, b in parts:
+                ids = [self.cls_token_id] + a.tolist() + [self.sep_token_id]
+                tt = [0] * len(ids)
+                if b is not None:
+                    ids += b.tolist() + [self.sep_token_id]
+                    tt += [1] * (len(b) + 1)
+                rows.append(ids)
+                types.append(tt)
+            return {"input_ids": rows, "attention_mask": [[1] * len(r) for r in rows], "token_type_ids": types}
+        n, width = len(parts), max(lens)
+        ids = np.full((n, width), self.pad_token_id, dtype=np.int64)
+        mask = np.zeros((n, width), dtype=np.int64)
+        types = np.zeros((n, width), dtype=np.int64)
+        for i, (a, b) in enumerate(parts):
+            la = len(a)
+            ids[i, 0] = self.cls_token_id
+            ids[i, 1: 1 + la] = a
+            ids[i, 1 + la] = self.sep_token_id
+            if b is not None:
+                lb = len(b)
+                ids[i, 2 + la: 2 + la + lb] = b
+                ids[i, 2 + la + lb] = self.sep_token_id
+                types[i, 2 + la: 3 + la + lb] = 1
+            mask[i, : lens[i]] = 1
+        out = {"input_ids": ids, "attention_mask": mask, "token_type_ids": types}
         if return_tensors == "pt":
-            out = {k: torch.from_numpy(np.asarray(v, dtype=np.int64)) for k, v in out.items()}
-        return out
+            return {k: torch.from_numpy(v) for k, v in out.items()}
+        return {k: v.tolist() for k, v in out.items()}
 
 
 # --------------------------------------------------------------------------- random models
