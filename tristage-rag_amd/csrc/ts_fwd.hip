@@ -1,14 +1,18 @@
-// Fused residual-add + LayerNorm for the cross-encoder / encoder forwards (gfx950).
+// HIP kernels between the GEMMs of the encoder forwards (gfx950): residual add + LayerNorm (post-LN and pre-LN), embedding
+// gather + LayerNorm, self-attention of a right-padded batch, rotary embedding, gated GELU.  The GEMMs themselves stay
+// with PyTorch-ROCm (BASELINE north_star); the host side that strings them together is tristage_rag_amd/encoders.py
+// (LeanBertEncoder / LeanBertClassifier / LeanModernBertEncoder).
 //
-// The transformer forwards of the path are PyTorch-ROCm GEMMs and attention (BASELINE north_star); what sits
-// BETWEEN the GEMMs of a post-LN encoder layer (BERT / RoBERTa / XLM-R: the cross-encoder the reference reaches
+// ---- fused residual add + LayerNorm
+// What sits BETWEEN the GEMMs of a post-LN encoder layer (BERT / RoBERTa / XLM-R: the cross-encoder the reference reaches
 // through CrossEncoder.predict, reference src/stage3_reranker.py:127-131) is three elementwise kernels under
 // autocast — residual add (bf16 + fp32 -> fp32), LayerNorm (fp32 -> fp32), cast for the next GEMM (fp32 -> bf16):
 // 24 bytes per element of HBM traffic.  At the batch sizes of search_many (1024 pairs x ~110 tokens x H = 384)
 // the activations are 10^8 elements and these passes are a fifth of the forward.  Here they are ONE pass:
 //     y = LayerNorm(x + residual) * gamma + beta      (statistics and arithmetic in fp32, like torch.layer_norm)
 // read x (16-bit or fp32) and the fp32 residual once, write y in fp32 (the next residual) and in the 16-bit type
-// (the next GEMM's input): 12 bytes per element.  One wave per row, the row in registers, two-pass mean / variance.
+// (the next GEMM's input): 12 bytes per element.  Persistent waves, one row per wave (two when a row is at most 96
+// four-element chunks), the row in registers, two-pass mean / variance, the next row's loads issued before the reductions.
 #include "ts_common.h"
 #include <initializer_list>
 
