@@ -147,12 +147,22 @@ def test_hip_graph_query_forwards_match_eager(tmp_path):
     for t in texts * 2:                                   # second round replays the captured graphs
         np.testing.assert_allclose(graph.encode(t), eager.encode(t), atol=1e-4)
     assert graph._graphed is not None and not graph._graphed._broken and len(graph._graphed._graphs) >= 3
+    # a BATCH of queries: padded to a (rows, length) bucket, replayed; twice (capture, then replay)
+    for _ in range(2):
+        np.testing.assert_allclose(graph.encode(texts[:4], batch_size=64), eager.encode(texts[:4], batch_size=64), atol=1e-4)
+        many = [f"query number {i} " + "w " * (i % 9) for i in range(37)]
+        np.testing.assert_allclose(graph.encode(many, batch_size=64), eager.encode(many, batch_size=64), atol=1e-4)
+    assert any(r > 1 for r, _ in graph._graphed._graphs)
     s_e = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cuda", use_fp16=False))
     s_g = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cuda", use_fp16=False, use_hip_graph=True))
     for t in texts:
         a, b = s_e.encode_query(t), s_g.encode_query(t)
         assert a.shape == b.shape
         assert torch.allclose(a, b, atol=1e-4)
+    for _ in range(2):
+        for a, b in zip(s_e.encode_queries_batch(texts[:4] * 5), s_g.encode_queries_batch(texts[:4] * 5)):
+            assert a.shape == b.shape and torch.allclose(a, b, atol=1e-4)
+    assert any(r > 1 for r, _ in s_g._graphed._graphs)
     # stage 3: one query's pairs as a single graph replay (rows and columns padded to a bucket)
     from tristage_rag_amd.encoders import CrossEncoderModel
     ce_e = CrossEncoderModel("random:tiny", device="cuda", use_amp=False)

@@ -257,23 +257,27 @@ def _lean_for_graph(model, amp_dtype, classifier: bool):
 
 
 class GraphedForward:
-    """Batch-1 encoder forwards replayed from captured HIP graphs.
+    """Small encoder forwards (one query, or a batch of up to 128 queries) replayed from captured HIP graphs.
 
     A single query through a 12-22 layer encoder is ~200 tiny kernels: launch-bound
     (4.6 ms eager vs 2.5 ms replayed for BERT-base, 8.1 vs 5.0 ms for ModernBERT-base on
-    MI355X, outputs bit-identical in tools/graph_probe.py).  The token sequence is padded
-    to the next length bucket (pad id + attention-mask 0, so valid positions are
-    unchanged), one graph per bucket is captured on first use and replayed afterwards.
-    If a model cannot be captured the eager GPU forward is used (and remembered)."""
+    MI355X with the transformers modules, outputs bit-identical in tools/graph_probe.py; the
+    written-out forwards: 3.4 ms eager for ModernBERT-base).  The batch is padded to a
+    (rows, length) bucket — extra columns are pad ids under attention-mask 0, extra rows a pad
+    row with one attended position, so valid positions are unchanged — one graph per bucket is
+    captured on first use and replayed afterwards.  The attention mask of the batch must be a
+    right-padding mask (what tokenizers produce).  If a model cannot be captured the eager GPU
+    forward is used (and remembered)."""
 
     BUCKETS = (8, 16, 32, 64, 128, 192, 256, 384, 512)
+    ROWS = (1, 8, 16, 32, 64, 128)
 
     def __init__(self, model, pad_token_id: int = 0, amp_dtype=None):
         self.model = model
         self.pad = int(pad_token_id or 0)
         self.amp_dtype = amp_dtype
         self.lean_forward = True      # capture the written-out forward (LeanBertEncoder / LeanModernBertEncoder) when there is one
-        self._graphs: Dict[int, Tuple[Any, torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._graphs: Dict[Tuple[int, int], Tuple[Any, torch.Tensor, torch.Tensor, torch.Tensor]] = {}
         self._broken = False
 
     def _run(self, ids: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -283,16 +287,16 @@ class GraphedForward:
         # outside any caller context and with the cache off (the casts become graph nodes).
         with torch.no_grad(), torch.autocast("cuda", enabled=False):
             lean = _lean_for_graph(self.model, self.amp_dtype, False) if self.lean_forward else None
-            if lean is not None:    # (the padded bucket's mask is a prefix mask by construction: no look at it on the host)
+            if lean is not None:    # (a right-padding mask: no look at it on the host)
                 return lean(ids, mask, None, lengths=mask.sum(1, dtype=torch.int32))
             if self.amp_dtype is not None:
                 with torch.autocast("cuda", dtype=self.amp_dtype, cache_enabled=False):
                     return self.model(input_ids=ids, attention_mask=mask).last_hidden_state
             return self.model(input_ids=ids, attention_mask=mask).last_hidden_state
 
-    def _capture(self, L: int, device):
-        ids = torch.full((1, L), self.pad, dtype=torch.long, device=device)
-        mask = torch.zeros((1, L), dtype=torch.long, device=device)
+    def _capture(self, R: int, L: int, device):
+        ids = torch.full((R, L), self.pad, dtype=torch.long, device=device)
+        mask = torch.zeros((R, L), dtype=torch.long, device=device)
         mask[:, 0] = 1
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -306,25 +310,28 @@ class GraphedForward:
         return g, ids, mask, out
 
     def __call__(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
-        """input_ids / attention_mask [1, n] on the GPU -> last_hidden_state [1, n, H] (a copy)."""
-        n = int(input_ids.shape[1])
+        """input_ids / attention_mask [B, n] on the GPU (right-padded) -> last_hidden_state [B, n, H] (a copy)."""
+        B, n = int(input_ids.shape[0]), int(input_ids.shape[1])
         bucket = next((b for b in self.BUCKETS if b >= n), None)
-        if self._broken or bucket is None or input_ids.shape[0] != 1:
+        rows = next((r for r in self.ROWS if r >= B), None)
+        if self._broken or bucket is None or rows is None:
             return self._run(input_ids, attention_mask)
-        if bucket not in self._graphs:
+        key = (rows, bucket)
+        if key not in self._graphs:
             try:
-                self._graphs[bucket] = self._capture(bucket, input_ids.device)
+                self._graphs[key] = self._capture(rows, bucket, input_ids.device)
             except Exception:
                 self._broken = True
                 torch.cuda.synchronize()
                 return self._run(input_ids, attention_mask)
-        g, ids, mask, out = self._graphs[bucket]
+        g, ids, mask, out = self._graphs[key]
         ids.fill_(self.pad)
         mask.zero_()
-        ids[:, :n].copy_(input_ids)
-        mask[:, :n].copy_(attention_mask)
+        mask[:, 0] = 1
+        ids[:B, :n].copy_(input_ids)
+        mask[:B, :n].copy_(attention_mask)
         g.replay()
-        return out[:, :n].clone()
+        return out[:B, :n].clone()
 
 
 class GraphedClassifier:
@@ -492,7 +499,8 @@ class SentenceEncoder:
             enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
                 enc.pop("token_type_ids")
-            if self.use_hip_graph and len(idx) == 1 and str(self.device).startswith("cuda"):
+            if (self.use_hip_graph and str(self.device).startswith("cuda") and
+                    (len(idx) == 1 or (len(idx) <= GraphedForward.ROWS[-1] and lengths is not None))):
                 if self._graphed is None:  # the autocast state of the first call is baked into the graphs
                     self._graphed = GraphedForward(
                         self.model, getattr(self.tokenizer, "pad_token_id", 0),

@@ -378,11 +378,23 @@ class ColBERTScorer:
         """Token matrices [Lq_j, H] of several queries from ONE padded forward (the reference
         encodes one query per call, :203-205; same values up to batch-padding noise)."""
         out: List[torch.Tensor] = []
-        if len(queries) == 1 and self.config.use_hip_graph and str(self.device).startswith("cuda"):
+        graphs = self.config.use_hip_graph and str(self.device).startswith("cuda")
+        if len(queries) == 1 and graphs:
             return [self._encode_single_text(queries[0])[0]]       # one query: the graph-replayed batch-1 forward
         bs = max(self.config.batch_size, 1)
+        if graphs:
+            from .encoders import GraphedForward
+            bs = max(bs, GraphedForward.ROWS[-1])                  # up to 128 queries per replayed forward
         for s in range(0, len(queries), bs):
             enc = self._tokenize_batch(list(queries[s:s + bs]))
+            if graphs and "lengths" in enc:                        # (a right-padding mask, checked on the host)
+                if self._graphed is None:
+                    self._graphed = GraphedForward(self.model, getattr(self.tokenizer, "pad_token_id", 0),
+                                                   torch.bfloat16 if self.use_amp else None)
+                hidden = self._graphed(enc["input_ids"], enc["attention_mask"])
+                lens = enc["lengths"].tolist()
+                out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))
+                continue
             hidden = self._forward(enc)
             lens = enc["attention_mask"].sum(dim=1).tolist()
             out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))
