@@ -226,6 +226,16 @@ def _autocast(device: str, enabled: bool, dtype=torch.bfloat16):
 
 
 # --------------------------------------------------------------------------- hipGraph replay
+def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
+    """Host tensor -> GPU through pinned memory without blocking the host: a plain ``.to(device)`` of pageable memory
+    waits for everything already queued on the stream (the previous batch's forward or scan), which serialises the host's
+    tokenising and launching with the GPU's work.  (torch's pinned-memory cache keeps the staging buffer alive until
+    the copy has run.)  Anything that is not a CPU tensor, or a non-GPU target, takes the ordinary path."""
+    if isinstance(t, torch.Tensor) and not t.is_cuda and str(device).startswith("cuda"):
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def _prefix_lengths(enc, tokenizer):
     """int32 [B] token counts of a tokenizer batch (still on the host) when its mask is a prefix mask — right padding,
     the tokenizers' default — else None.  Handed to the written-out forwards so that they need not inspect the mask on
@@ -496,7 +506,7 @@ class SentenceEncoder:
             enc = self.tokenizer([texts[i] for i in idx], truncation=True, padding=True,
                                  max_length=self.max_seq_length, return_tensors="pt")
             lengths = _prefix_lengths(enc, self.tokenizer)
-            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            enc = {k: to_device_async(v, self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             if "token_type_ids" in enc and not hasattr(self.model.config, "type_vocab_size"):
                 enc.pop("token_type_ids")
             if (self.use_hip_graph and str(self.device).startswith("cuda") and
@@ -511,7 +521,7 @@ class SentenceEncoder:
                 if self.lean_forward and str(self.device).startswith("cuda") and torch.is_autocast_enabled("cuda"):
                     lean = lean_encoder_for(self.model, torch.get_autocast_dtype("cuda"))
                 hidden = (lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"),
-                               lengths=lengths.to(self.device) if lengths is not None else None) if lean
+                               lengths=to_device_async(lengths, self.device) if lengths is not None else None) if lean
                           else self.model(**enc).last_hidden_state)
             emb = self._pool(hidden.float(), enc["attention_mask"])
             for d in self.dense:
@@ -519,7 +529,7 @@ class SentenceEncoder:
             if self.normalize or normalize_embeddings:
                 emb = F.normalize(emb, p=2, dim=1)
             # back into the caller's order: one scatter per batch (not one tiny copy per text)
-            res[torch.as_tensor(np.ascontiguousarray(idx), device=res.device)] = emb.float()
+            res[to_device_async(torch.from_numpy(np.ascontiguousarray(idx)), res.device)] = emb.float()
         if single:
             res = res[0]
         if convert_to_tensor:
@@ -1078,7 +1088,7 @@ class CrossEncoderModel:
             # one query's pairs: a single forward replayed from a HIP graph
             enc = self.tokenizer([p[0] for p in pairs], [p[1] for p in pairs], truncation=True, padding=True,
                                  max_length=self.max_length, return_tensors="pt")
-            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            enc = {k: to_device_async(v, self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             lg = self.logits_graphed(enc)
             if lg is not None:
                 return lg.reshape(len(pairs), -1)
@@ -1087,11 +1097,11 @@ class CrossEncoderModel:
             enc = self.tokenizer([pairs[i][0] for i in idx], [pairs[i][1] for i in idx], truncation=True,
                                  padding=True, max_length=self.max_length, return_tensors="pt")
             lengths = _prefix_lengths(enc, self.tokenizer)
-            enc = {k: v.to(self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
+            enc = {k: to_device_async(v, self.device) for k, v in enc.items() if k in ("input_ids", "attention_mask", "token_type_ids")}
             if lengths is not None:
-                enc["lengths"] = lengths.to(self.device)
+                enc["lengths"] = to_device_async(lengths, self.device)
             lg = self.logits_from_ids(enc)        # the written-out forward when there is one, else the module under AMP
-            res[torch.as_tensor(np.ascontiguousarray(idx), device=self.device)] = lg.reshape(len(idx), -1)
+            res[to_device_async(torch.from_numpy(np.ascontiguousarray(idx)), self.device)] = lg.reshape(len(idx), -1)
         return res
 
     def logits_graphed(self, enc: Dict[str, torch.Tensor]) -> Optional[torch.Tensor]:

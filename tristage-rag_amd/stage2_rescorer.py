@@ -150,7 +150,8 @@ class ColBERTScorer:
     # -- encoding ------------------------------------------------------------
     def _model_inputs(self, enc: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         keep = ("input_ids", "attention_mask", "token_type_ids")
-        out = {k: v.to(self.device) for k, v in enc.items() if k in keep}
+        from .encoders import to_device_async
+        out = {k: to_device_async(v, self.device) for k, v in enc.items() if k in keep}
         if "token_type_ids" in out and not hasattr(self.model.config, "type_vocab_size"):
             out.pop("token_type_ids")
         return out
@@ -174,11 +175,11 @@ class ColBERTScorer:
         texts = [t if t and t.strip() else "empty" for t in texts]
         enc = self.tokenizer(texts, truncation=True, padding=True, max_length=self.config.max_seq_length,
                              return_tensors="pt")
-        from .encoders import _prefix_lengths
+        from .encoders import _prefix_lengths, to_device_async
         lengths = _prefix_lengths(enc, self.tokenizer)      # on the host: the written-out forward then needs no mask check
         out = self._model_inputs(enc)
         if lengths is not None:
-            out["lengths"] = lengths.to(self.device)
+            out["lengths"] = to_device_async(lengths, self.device)
         return out
 
     def _pool_embeddings(self, embeddings: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
