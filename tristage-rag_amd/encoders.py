@@ -281,6 +281,7 @@ class GraphedForward:
 
     BUCKETS = (8, 16, 32, 64, 128, 192, 256, 384, 512)
     ROWS = (1, 8, 16, 32, 64, 128)
+    MAX_BATCH_TOKENS = 16384          # rows x length bucket of a batch graph (query batches are short)
 
     def __init__(self, model, pad_token_id: int = 0, amp_dtype=None):
         self.model = model
@@ -324,8 +325,8 @@ class GraphedForward:
         B, n = int(input_ids.shape[0]), int(input_ids.shape[1])
         bucket = next((b for b in self.BUCKETS if b >= n), None)
         rows = next((r for r in self.ROWS if r >= B), None)
-        if self._broken or bucket is None or rows is None:
-            return self._run(input_ids, attention_mask)
+        if self._broken or bucket is None or rows is None or (rows > 1 and rows * bucket > self.MAX_BATCH_TOKENS):
+            return self._run(input_ids, attention_mask)       # (big batches are not launch-bound; their graphs would pin GBs)
         key = (rows, bucket)
         if key not in self._graphs:
             try:
