@@ -79,7 +79,7 @@ __device__ __forceinline__ void ln_fetch(const LnParams& p, int64_t row, int lir
       v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (e < p.H) {
         v[c] = ln_load4<XDT>(p.x, base + e);
-        if (p.res) v[c] += *reinterpret_cast<const f32x4*>(p.res + base + e);
+        if (p.res) v[c] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.res + base + e));   // read once
       }
     }
   }
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
       const int e = (c * LPR + lir) * 4;
       if (e < H) {
         const f32x4 y = (v[c] - mean) * rstd * g[c] + bt[c];
-        if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + base + e) = p.prenorm ? v[c] : y;
+        // (the fp32 stream is next read two GEMMs later: it need not displace the 16-bit copy the next GEMM reads at once)
+        if (p.out_f32) __builtin_nontemporal_store(p.prenorm ? v[c] : y, reinterpret_cast<f32x4*>(p.out_f32 + base + e));
         if (p.out_lp) {
           uint2 pk;
           pk.x = ln_pack2(y[0], y[1], p.lp_dt);
