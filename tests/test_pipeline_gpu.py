@@ -526,3 +526,45 @@ def test_attention_varlen_random_shapes_sweep():
                 err = float((out.float() - want)[valid].abs().max())
                 assert err <= 3 * step * max(1.0, float(want[valid].abs().max())), (B, L, nh, dh, window, err)
             assert bool((out[~valid] == 3.0).all()), (B, L, nh, dh)
+
+
+@pytest.mark.parametrize("amp", ["bf16", "fp16"])
+def test_amp_dtype_option_runs_the_forwards_and_the_token_store_in_that_type(tmp_path, amp):
+    """PipelineConfig.amp_dtype: "fp16" is the reference's own GPU precision (torch.cuda.amp.autocast), "bf16" the
+    BASELINE configs[2] setting.  Either way the written-out forwards and the token store use that 16-bit type, the
+    array path and the record path agree, and the top results overlap with the fp32 (parity-setting) pipeline's."""
+    import torch
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    docs = _corpus(700)
+    queries = ["neural network attention", "gpu memory index", docs[5], "language model retrieval"]
+
+    def build(name, **kw):
+        pc = PipelineConfig(stage1_model="random:minilm", stage2_model="random:modernbert:64:4:2", stage3_model="random:minilm",
+                            device="cuda", cache_dir=str(tmp_path / "m"), index_dir=str(tmp_path / name),
+                            log_file=str(tmp_path / f"{name}.log"), log_level="WARNING", stage1_top_k=200, stage2_top_k=40,
+                            stage3_top_k=10, stage1_enable_bm25=False, stage2_precompute_document_embeddings=True,
+                            stage3_cache_document_tokens=True, **kw)
+        p = RetrievalPipeline(config=pc)
+        p.add_documents(docs)
+        return p
+    want = torch.bfloat16 if amp == "bf16" else torch.float16
+    p = build("amp", amp_dtype=amp)
+    assert p.stage2.token_store.data.dtype == want
+    res = p.search_many(queries)
+    assert all(len(r["results"]) == 10 for r in res)
+    for m in (p.stage1.model.model, p.stage2.model):
+        assert want in m.__dict__.get("_ts_lean_encoders", {})            # the written-out forward in that type
+    assert p.stage3.model._lean and p.stage3.model._lean.cd == want
+    one = [p.search(q) for q in queries]                                 # array path for one query
+    p.config.search_on_arrays = False
+    rec = [p.search(q) for q in queries]                                 # per-record path
+    for a, b, c in zip(res, one, rec):
+        ia, ib, ic = ([x["doc_id"] for x in r["results"]] for r in (a, b, c))
+        assert len(set(ia) & set(ib)) >= 9 and len(set(ia) & set(ic)) >= 8   # batch-padding / tokenised-vs-assembled noise
+    ref = build("f32", stage1_use_fp16=False, stage2_use_fp16=False, stage3_use_fp16=False)
+    for a, b in zip(res, ref.search_many(queries)):
+        top_ref = [x["doc_id"] for x in b["stage1_results"][:5]] if b["stage1_results"] else None
+        ia, ib = ([x["doc_id"] for x in r["results"]] for r in (a, b))
+        assert len(set(ia) & set(ib)) >= 6, (amp, ia, ib)                 # 16-bit forwards of random-init models vs fp32
+    with pytest.raises(ValueError):
+        build("bad", amp_dtype="fp8")

@@ -70,6 +70,8 @@ class PipelineConfig:
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
     stage2_token_store_dtype: str = "auto"   # "auto": bf16 under AMP, else the encoder's output type; or bf16 | f16 | f32
+    amp_dtype: str = "bf16"                     # what stage*_use_fp16 means on the GPU: "bf16" (BASELINE configs[2]) or "fp16"
+                                                # (what torch.cuda.amp.autocast() gives the reference on a GPU)
     stage1_index_batch_size: int = 256          # documents per encoder forward at add_documents time (stage 1, device path)
     stage2_index_batch_size: int = 256          # ... and for the stage-2 token store
     search_on_arrays: bool = True               # search() takes the array path of search_many when its preconditions hold
@@ -160,7 +162,7 @@ class RetrievalPipeline:
                 enable_bm25=c.stage1_enable_bm25, bm25_top_k=c.stage1_bm25_top_k,
                 fusion_method=c.stage1_fusion_method, use_fp16=c.stage1_use_fp16,
                 index_dtype=c.stage1_index_dtype, bm25_on_gpu=c.stage1_bm25_on_gpu,
-                use_hip_graph=c.use_hip_graphs, index_batch_size=c.stage1_index_batch_size))
+                use_hip_graph=c.use_hip_graphs, index_batch_size=c.stage1_index_batch_size, amp_dtype=c.amp_dtype))
             self.logger.info("Stage 1 initialized")
             self.stage2 = ColBERTScorer(Stage2Config(
                 model_name=c.stage2_model, device=c.device, cache_dir=c.cache_dir,
@@ -170,13 +172,13 @@ class RetrievalPipeline:
                 cache_document_embeddings=c.stage2_cache_document_embeddings,
                 precompute_document_embeddings=c.stage2_precompute_document_embeddings,
                 token_store_dtype=c.stage2_token_store_dtype,
-                use_hip_graph=c.use_hip_graphs, index_batch_size=c.stage2_index_batch_size))
+                use_hip_graph=c.use_hip_graphs, index_batch_size=c.stage2_index_batch_size, amp_dtype=c.amp_dtype))
             self.logger.info("Stage 2 initialized")
             self.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
                 max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
                 top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs,
-                many_batch_size=c.stage3_many_batch_size))
+                many_batch_size=c.stage3_many_batch_size, amp_dtype=c.amp_dtype))
             self.logger.info("Stage 3 initialized")
         except Exception as e:
             self.logger.error(f"Error initializing pipeline stages: {e}")

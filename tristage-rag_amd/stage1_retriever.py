@@ -42,6 +42,8 @@ class Stage1Config:
     top_k_candidates: int = 500
     batch_size: int = 32
     index_batch_size: int = 256     # additive: documents per encoder forward in add_documents on the device path
+    amp_dtype: str = "bf16"         # additive: what use_fp16 means on the GPU — "bf16" (BASELINE configs[2]) or "fp16"
+                                    # (what torch.cuda.amp.autocast() gives the reference, :235)
     max_text_length: int = 512
     enable_bm25: bool = True
     bm25_top_k: int = 300
@@ -58,6 +60,17 @@ class Stage1Config:
     bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM + HIP scoring kernels; None = whenever
                                         # the HIP index is in use (a GPU is present)
     use_hip_graph: bool = False  # replay single-query encoder forwards from HIP graphs
+
+
+def amp_torch_dtype(name: str):
+    """"bf16" / "fp16" (also "bfloat16", "f16", "float16", "half") -> the torch dtype of the AMP forwards."""
+    import torch
+    key = str(name).lower()
+    if key in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if key in ("fp16", "f16", "float16", "half"):
+        return torch.float16
+    raise ValueError(f"amp_dtype must be 'bf16' or 'fp16', not {name!r}")
 
 
 class BM25Index:
@@ -278,12 +291,16 @@ class Stage1Retriever:
             self.embedding_dim = int(np.asarray(self.model.encode("sample text", convert_to_numpy=True)).shape[0])
         self.logger.info(f"Model loaded successfully. Embedding dimension: {self.embedding_dim}")
 
+    def _amp_dtype(self):
+        import torch
+        return amp_torch_dtype(getattr(self.config, "amp_dtype", "bf16"))
+
     def _encode_batch(self, texts: List[str]) -> np.ndarray:
         """reference :230-254 — float32 [n, d] embeddings (AMP on the GPU when use_fp16)."""
         import torch
         dev = str(getattr(self.model, "device", "cpu"))
         if self.config.use_fp16 and dev.startswith("cuda"):
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.autocast("cuda", dtype=self._amp_dtype()):
                 emb = self.model.encode(texts, batch_size=self.config.batch_size, convert_to_numpy=True,
                                         show_progress_bar=False)
         else:
@@ -313,7 +330,7 @@ class Stage1Retriever:
 
     def _encode_batch_tensor(self, texts: List[str], bulk: bool = False):
         import torch
-        ctx = (torch.autocast("cuda", dtype=torch.bfloat16) if self.config.use_fp16
+        ctx = (torch.autocast("cuda", dtype=self._amp_dtype()) if self.config.use_fp16
                else torch.autocast("cuda", enabled=False))
         bs = max(self.config.batch_size, getattr(self.config, "index_batch_size", 0) or 0) if bulk else self.config.batch_size
         with ctx:

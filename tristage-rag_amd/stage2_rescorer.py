@@ -44,6 +44,7 @@ class Stage2Config:
                                                   # encoder runs under AMP (its last LayerNorm hands back fp32 even
                                                   # then), else the encoder's own output type; or "bf16" | "f16" | "f32"
     use_hip_graph: bool = False                   # replay the batch-1 query forward from a HIP graph
+    amp_dtype: str = "bf16"                       # what use_fp16 means on the GPU: "bf16" or "fp16" (the reference's autocast)
     index_batch_size: int = 256                   # documents per forward wherever MANY documents are encoded: filling the
                                                   # token store at add time, re-encoding a query's candidates without one
                                                   # (batch_size, the reference's 16, keeps both launch-bound)
@@ -156,6 +157,10 @@ class ColBERTScorer:
             out.pop("token_type_ids")
         return out
 
+    def _amp_dtype(self):
+        from .stage1_retriever import amp_torch_dtype
+        return amp_torch_dtype(getattr(self.config, "amp_dtype", "bf16"))
+
     def _forward(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
         lengths = enc.get("lengths")
         enc = {k: v for k, v in enc.items() if k != "lengths"}
@@ -163,10 +168,10 @@ class ColBERTScorer:
             if self.use_amp:
                 if getattr(self, "lean_forward", True):
                     from .encoders import lean_encoder_for   # BERT-family / ModernBERT token encoders: the written-out forward
-                    lean = lean_encoder_for(self.model, torch.bfloat16)
+                    lean = lean_encoder_for(self.model, self._amp_dtype())
                     if lean:
                         return lean(enc["input_ids"], enc["attention_mask"], enc.get("token_type_ids"), lengths=lengths)
-                with torch.autocast("cuda", dtype=torch.bfloat16):
+                with torch.autocast("cuda", dtype=self._amp_dtype()):
                     return self.model(**enc).last_hidden_state
             return self.model(**enc).last_hidden_state
 
@@ -206,7 +211,7 @@ class ColBERTScorer:
             if self._graphed is None:
                 from .encoders import GraphedForward
                 self._graphed = GraphedForward(self.model, getattr(self.tokenizer, "pad_token_id", 0),
-                                               torch.bfloat16 if self.use_amp else None)
+                                               self._amp_dtype() if self.use_amp else None)
             return self._graphed(enc["input_ids"], enc["attention_mask"])  # unpadded input: all tokens valid
         hidden = self._forward(enc)
         n = int(enc["attention_mask"].sum().item())
@@ -282,7 +287,7 @@ class ColBERTScorer:
     def store_dtype(self) -> Optional[torch.dtype]:
         name = self.config.token_store_dtype
         if name == "auto":
-            return torch.bfloat16 if self.use_amp else None
+            return self._amp_dtype() if self.use_amp else None
         return {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[name]
 
     def index_documents(self, documents: List[str], first_doc_id: int) -> None:
@@ -391,7 +396,7 @@ class ColBERTScorer:
             if graphs and "lengths" in enc:                        # (a right-padding mask, checked on the host)
                 if self._graphed is None:
                     self._graphed = GraphedForward(self.model, getattr(self.tokenizer, "pad_token_id", 0),
-                                                   torch.bfloat16 if self.use_amp else None)
+                                                   self._amp_dtype() if self.use_amp else None)
                 hidden = self._graphed(enc["input_ids"], enc["attention_mask"])
                 lens = enc["lengths"].tolist()
                 out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))

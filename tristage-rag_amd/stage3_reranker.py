@@ -35,6 +35,7 @@ class Stage3Config:
     # additive
     use_hip_graph: bool = False  # one query's pairs as a single forward replayed from a HIP graph
     many_batch_size: int = 1024  # pairs per forward when several queries are reranked together (rerank_many)
+    amp_dtype: str = "bf16"      # what use_fp16 means on the GPU: "bf16" or "fp16" (the reference's autocast)
 
 
 class CrossEncoderReranker:
@@ -60,13 +61,17 @@ class CrossEncoderReranker:
             self.model = CrossEncoderModel(self.config.model_name, device=self.device,
                                            max_length=self.config.max_length,
                                            cache_folder=self.config.cache_dir,
-                                           use_amp=self.config.use_fp16,
+                                           use_amp=self.config.use_fp16, amp_dtype=self._amp_dtype(),
                                            use_hip_graph=self.config.use_hip_graph)
         # CrossEncoder-style object (predict on sentence pairs), like the reference's preferred path
         self.use_sentence_transformers = hasattr(self.model, "predict")
         if not self.use_sentence_transformers:
             self.tokenizer = getattr(self.model, "tokenizer", None)
         self.use_amp = self.config.use_fp16 and str(self.device).startswith("cuda")
+
+    def _amp_dtype(self):
+        from .stage1_retriever import amp_torch_dtype
+        return amp_torch_dtype(getattr(self.config, "amp_dtype", "bf16"))
 
     def _prepare_input_pairs(self, query: str, documents: List[str]) -> List[Tuple[str, str]]:
         return [(query, doc) for doc in documents]
@@ -87,7 +92,7 @@ class CrossEncoderReranker:
             enc = {k: v.to(self.device) for k, v in enc.items()}
             with torch.no_grad():
                 if self.use_amp:
-                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                    with torch.autocast("cuda", dtype=self._amp_dtype()):
                         logits = self.model(**enc).logits
                 else:
                     logits = self.model(**enc).logits
