@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--s3-batch", type=int, default=1024, help="pairs per cross-encoder forward in search_many")
     ap.add_argument("--no-lean", action="store_true", help="stage 3 through the transformers module instead of the written-out forward")
     ap.add_argument("--torch-attention", action="store_true", help="stage 3 attention through torch's masked SDPA instead of ts_attention_varlen")
+    ap.add_argument("--tune-gemms", action="store_true", help="PyTorch TunableOp for the GEMMs (stage-3 widths padded to multiples of 16; "
+                    "one untimed pass over the queries first, so that every shape is tuned before the timed region)")
     ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
@@ -55,7 +57,8 @@ def main():
                         stage3_batch_size=64, stage2_cache_document_embeddings=args.cache,
                         stage2_precompute_document_embeddings=args.store, use_hip_graphs=args.graphs,
                         stage3_cache_document_tokens=args.ids, save_intermediate_results=args.keep,
-                        stage3_many_batch_size=args.s3_batch)
+                        stage3_many_batch_size=args.s3_batch, tune_gemms=args.tune_gemms,
+                        stage3_width_multiple=16 if args.tune_gemms else 1)
     p = RetrievalPipeline(config=pc)
     p.initialize_stages()
     if args.no_lean and hasattr(p.stage3.model, "lean_forward"):
@@ -74,6 +77,17 @@ def main():
     if args.many:
         p.search_many(queries[: args.many])   # warm-up of the batched shapes
         torch.cuda.synchronize()
+    t_tune = None
+    if args.tune_gemms:                       # every GEMM shape of the run meets the tuner once, untimed
+        tt = time.perf_counter()
+        if args.many:
+            for s in range(0, len(queries), args.many):
+                p.search_many(queries[s: s + args.many])
+        else:
+            for q in queries:
+                p.search(q)
+        torch.cuda.synchronize()
+        t_tune = time.perf_counter() - tt
     prof = None
     if args.cprofile:
         import cProfile
@@ -110,7 +124,7 @@ def main():
                    "stage3_lean_forward": bool(getattr(p.stage3.model, "_lean", None)), "save_intermediate_results": args.keep,
                    "array_path": bool(args.ids and args.store and getattr(p.stage3, "_pairs_usable", False)
                                       and (args.many or p.config.search_on_arrays))},
-        "index_build_s": round(t_index, 3),
+        "index_build_s": round(t_index, 3), "gemm_tuning_pass_s": (round(t_tune, 1) if t_tune is not None else None),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,
         "data": "synthetic"}))

@@ -603,6 +603,14 @@ def test_search_many_on_arrays_equals_the_record_path(encoder, tmp_path, bm25, f
     for x, y in zip(lean, ra):
         assert x["stage1_results"] == [] and x["stage2_results"] == []
         assert [r["doc_id"] for r in x["results"]] == [r["doc_id"] for r in y["results"]]
+    # stage-3 batch widths padded to a multiple (fewer GEMM shapes for tune_gemms): masked padding, same ranking
+    a.stage3.config.many_width_multiple = 16
+    wide = a.search_many(qs, top_k=5)
+    a.stage3.config.many_width_multiple = 1
+    for x, y in zip(wide, ra):
+        assert [r["doc_id"] for r in x["results"]] == [r["doc_id"] for r in y["results"]]
+        for u, v in zip(x["results"], y["results"]):
+            assert u["stage3_score"] == pytest.approx(v["stage3_score"], abs=1e-5)
     # search() takes the same path for one query; search_on_arrays=False restores the per-record path
     took.clear()
     one = a.search(qs[1], top_k=5)

@@ -74,6 +74,12 @@ class PipelineConfig:
                                                 # (what torch.cuda.amp.autocast() gives the reference on a GPU)
     stage1_index_batch_size: int = 256          # documents per encoder forward at add_documents time (stage 1, device path)
     stage2_index_batch_size: int = 256          # ... and for the stage-2 token store
+    tune_gemms: bool = False                    # PyTorch TunableOp: the fastest hipBLASLt / rocBLAS solution per GEMM shape,
+                                                # found by timing at the shape's first occurrence (~1 s each, kept in the
+                                                # process and in tune_gemms_file): the 1024-pair stage-3 forward 9.6 -> 8.7 ms
+    tune_gemms_file: str = ""                   # results file (read at start, written at exit); "" = TunableOp's default name
+    stage3_width_multiple: int = 1              # pad the token width of search_many's stage-3 batches to a multiple of this
+                                                # (16 with tune_gemms: bounds the number of GEMM shapes to tune)
     search_on_arrays: bool = True               # search() takes the array path of search_many when its preconditions hold
     stage3_cache_document_tokens: bool = False  # tokenise every document once at add time; search_many then assembles
                                                 # the cross-encoder inputs from token ids on the GPU
@@ -155,6 +161,13 @@ class RetrievalPipeline:
     def initialize_stages(self) -> None:
         self.logger.info("Initializing pipeline stages...")
         c = self.config
+        if c.tune_gemms:
+            import torch
+            if torch.cuda.is_available():
+                if c.tune_gemms_file:
+                    torch.cuda.tunable.set_filename(c.tune_gemms_file)
+                torch.cuda.tunable.enable(True)
+                torch.cuda.tunable.tuning_enable(True)
         try:
             self.stage1 = Stage1Retriever(Stage1Config(
                 model_name=c.stage1_model, device=c.device, cache_dir=c.cache_dir, index_dir=c.index_dir,
@@ -178,7 +191,8 @@ class RetrievalPipeline:
                 model_name=c.stage3_model, device=c.device, cache_dir=c.cache_dir,
                 max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
                 top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs,
-                many_batch_size=c.stage3_many_batch_size, amp_dtype=c.amp_dtype))
+                many_batch_size=c.stage3_many_batch_size, amp_dtype=c.amp_dtype,
+                many_width_multiple=c.stage3_width_multiple))
             self.logger.info("Stage 3 initialized")
         except Exception as e:
             self.logger.error(f"Error initializing pipeline stages: {e}")

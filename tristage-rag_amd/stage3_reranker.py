@@ -36,6 +36,7 @@ class Stage3Config:
     use_hip_graph: bool = False  # one query's pairs as a single forward replayed from a HIP graph
     many_batch_size: int = 1024  # pairs per forward when several queries are reranked together (rerank_many)
     amp_dtype: str = "bf16"      # what use_fp16 means on the GPU: "bf16" or "fp16" (the reference's autocast)
+    many_width_multiple: int = 1  # rerank_arrays pads the token width of a batch to a multiple of this (fewer GEMM shapes)
 
 
 class CrossEncoderReranker:
@@ -223,6 +224,9 @@ class CrossEncoderReranker:
         raw = torch.empty((B * C,), dtype=torch.float32, device=dev)
         bs = max(self.config.batch_size, self.config.many_batch_size)
         widths = plan["total"][order[::bs]].tolist()          # one host sync: the padded width of every batch
+        wm = max(int(getattr(self.config, "many_width_multiple", 1) or 1), 1)
+        if wm > 1:                                            # (padding is masked: same scores up to batch-padding noise)
+            widths = [min(-(-int(w) // wm) * wm, max(int(self.config.max_length), int(w))) for w in widths]
         for j, s in enumerate(range(0, B * C, bs)):
             sel = order[s: s + bs]
             enc = pa.batch(plan, sel, width=int(widths[j]))
