@@ -91,3 +91,42 @@ def test_scores_entry_point_validates_arguments_without_a_gpu():
     lib = _lib.load()
     assert lib.ts_index_scores(None, None, 1, 0, None, 32, None) == _lib.TS_ERR_INVALID
     assert lib.ts_maxsim_release_scratch(-1) == _lib.TS_OK          # nothing allocated: nothing to free
+
+
+def test_forward_kernel_entry_points_validate_arguments_without_a_gpu():
+    """ts_add_layernorm / ts_add_prenorm / ts_embed_layernorm / ts_attention_varlen / ts_rope_inplace / ts_geglu and
+    ts_bm25_search_batch: bad arguments and unsupported shapes are reported before any HIP call; empty inputs are fine."""
+    from tristage_rag_amd import _lib
+    lib = _lib.load()
+    p = ctypes.c_void_p(4096)            # aligned, never dereferenced
+    odd = ctypes.c_void_p(4100)          # not 16-byte aligned
+    f = ctypes.c_float(1e-5)
+    BF, F16, F32 = _lib.TS_BF16, _lib.TS_F16, _lib.TS_F32
+    for fn in (lib.ts_add_layernorm, lib.ts_add_prenorm):
+        assert fn(None, BF, None, p, p, f, 4, 64, p, None, BF, 0, None) == _lib.TS_ERR_INVALID          # no input
+        assert fn(p, 9, None, p, p, f, 4, 64, p, None, BF, 0, None) == _lib.TS_ERR_INVALID             # bad dtype
+        assert fn(p, BF, None, p, p, f, 4, 64, None, None, BF, 0, None) == _lib.TS_ERR_INVALID         # no output
+        assert fn(p, BF, None, p, p, f, 4, 66, p, None, BF, 0, None) == _lib.TS_ERR_UNSUPPORTED        # H % 4
+        assert fn(p, BF, None, p, p, f, 4, 4096, p, None, BF, 0, None) == _lib.TS_ERR_UNSUPPORTED      # H > 2048
+        assert fn(odd, BF, None, p, p, f, 4, 64, p, None, BF, 0, None) == _lib.TS_ERR_UNSUPPORTED      # alignment
+        assert fn(p, BF, None, p, p, f, 0, 64, p, None, BF, 0, None) == _lib.TS_OK                     # no rows
+    assert lib.ts_embed_layernorm(None, p, None, p, p, p, p, p, f, 4, 64, p, None, BF, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_embed_layernorm(p, p, None, p, p, p, p, None, f, 4, 62, p, None, BF, 0, None) == _lib.TS_ERR_UNSUPPORTED
+    assert lib.ts_embed_layernorm(p, p, None, p, p, p, p, None, f, 0, 64, p, None, BF, 0, None) == _lib.TS_OK
+    one = ctypes.c_float(0.125)
+    assert lib.ts_attention_varlen(None, p, 2, 64, 4, 32, BF, one, 0, p, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, F32, one, 0, p, 0, None) == _lib.TS_ERR_INVALID     # 16-bit types only
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, BF, one, -1, p, 0, None) == _lib.TS_ERR_INVALID     # negative window
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 48, BF, one, 0, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # head dimension
+    assert lib.ts_attention_varlen(p, p, 2, 4096, 4, 64, BF, one, 0, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # K, V^T beyond LDS
+    assert lib.ts_attention_varlen(p, p, 70000, 64, 4, 32, BF, one, 0, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # grid limit
+    assert b"attention_varlen" in lib.ts_last_error()
+    assert lib.ts_attention_varlen(p, p, 0, 64, 4, 32, BF, one, 0, p, 0, None) == _lib.TS_OK
+    assert lib.ts_rope_inplace(None, BF, p, p, 2, 64, 4, 32, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_rope_inplace(p, F32, p, p, 2, 64, 4, 32, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_rope_inplace(p, BF, p, p, 2, 64, 4, 36, 0, None) == _lib.TS_ERR_UNSUPPORTED
+    assert lib.ts_rope_inplace(p, BF, p, p, 0, 64, 4, 32, 0, None) == _lib.TS_OK
+    assert lib.ts_geglu(None, BF, 4, 64, p, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_geglu(p, BF, 4, 60, p, 0, None) == _lib.TS_ERR_UNSUPPORTED
+    assert lib.ts_geglu(p, BF, 0, 64, p, 0, None) == _lib.TS_OK
+    assert lib.ts_bm25_search_batch(None, p, p, 1, 5, p, p, p, None) == _lib.TS_ERR_INVALID
