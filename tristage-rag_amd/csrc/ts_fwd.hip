@@ -162,7 +162,7 @@ static int ln_launch(const LnParams& p, hipStream_t s) {
   if (half) {
     if (nch <= 1) LN_GO(1, 32); else if (nch <= 2) LN_GO(2, 32); else LN_GO(3, 32);
   } else {
-    if (nch <= 2) LN_GO(2, 64); else if (nch <= 4) LN_GO(4, 64); else LN_GO(LN_MAX_CHUNKS, 64);
+    if (nch <= 2) LN_GO(2, 64); else if (nch <= 3) LN_GO(3, 64); else if (nch <= 4) LN_GO(4, 64); else LN_GO(LN_MAX_CHUNKS, 64);
   }
 #undef LN_GO
   const hipError_t e = hipGetLastError();
