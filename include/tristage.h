@@ -280,10 +280,14 @@ int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t
  * head must fit the 160 KB of LDS: L <= 1120 at dh 32, L <= 576 at dh 64;
  * pointers 16-byte aligned, B <= 65535.  window > 0: query q only sees the keys k with
  * |q - k| <= window (the bidirectional sliding window of ModernBERT's local layers:
- * window = local_attention / 2); 0 = all keys.                                      */
+ * window = local_attention / 2); 0 = all keys.  rope_cos / rope_sin (fp32 [L, dh], both or
+ * neither): the rotary embedding of ts_rope_inplace applied to q and k as they are
+ * loaded — same arithmetic, same results as ts_rope_inplace followed by this call
+ * without tables, minus one pass over q and k (qkv itself is left as it is).         */
 int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads,
-                        int32_t dh, int32_t dtype, float scale, int32_t window, void* out,
-                        int32_t device, void* stream);
+                        int32_t dh, int32_t dtype, float scale, int32_t window,
+                        const float* rope_cos, const float* rope_sin, void* out, int32_t device,
+                        void* stream);
 
 /* Rotary position embedding of the q and k thirds of qkv [B, L, 3, heads, dh] in place:
  * x <- x * cos + rotate_half(x) * sin with fp32 tables cos / sin [L, dh] (row = token

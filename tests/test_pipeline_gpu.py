@@ -455,6 +455,23 @@ def test_rope_geglu_prenorm_and_window_kernels_match_torch(dt):
         want_a = (torch.softmax(s, -1) @ v.float()).transpose(1, 2).reshape(B, L, H)
         got_a = attention_varlen(qkv, lens, nh, window=window)
         assert float((got_a.float() - want_a)[valid].abs().max()) <= 3 * step * float(want_a[valid].abs().max())
+        # rotary embedding applied inside the attention kernel == rope_inplace first, then the plain kernel: bit for bit
+        rotated = rope_inplace(qkv.clone(), cos, sin, nh)
+        two_pass = attention_varlen(rotated, lens, nh, window=window)
+        before = qkv.clone()
+        fused = attention_varlen(qkv, lens, nh, window=window, rope=(cos, sin))
+        assert torch.equal(fused, two_pass) and torch.equal(qkv, before)       # (qkv itself is left alone)
+    for nh2, dh2 in ((4, 32), (1, 64)):                                        # the other head dimension, short rows
+        L2 = 70
+        qkv2 = torch.randn((3, L2, 3 * nh2 * dh2), generator=g, device="cuda").to(tdt)
+        ang2 = torch.rand((L2, dh2 // 2), generator=g, device="cuda") * 6.28
+        c2_, s2_ = torch.cat((ang2.cos(), ang2.cos()), -1).contiguous(), torch.cat((ang2.sin(), ang2.sin()), -1).contiguous()
+        lens2 = torch.tensor([L2, 33, 1], dtype=torch.int32, device="cuda")
+        a1 = attention_varlen(rope_inplace(qkv2.clone(), c2_, s2_, nh2), lens2, nh2)
+        a2 = attention_varlen(qkv2, lens2, nh2, rope=(c2_, s2_))
+        assert torch.equal(a1, a2)
+    with pytest.raises(ValueError):
+        attention_varlen(qkv, lens, nh, rope=(cos[:, :-8].contiguous(), sin))
 
 
 def test_lean_modernbert_on_gpu_matches_module_under_autocast():

@@ -280,6 +280,42 @@ template <int DT> __device__ __forceinline__ uint32_t fw_pack2v(fw_f2 v) {     /
 }
 
 
+template <int DT> __device__ __forceinline__ float fw_to_f32(uint16_t v) {
+  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __uint_as_float((uint32_t)v << 16);
+}
+template <int DT> __device__ __forceinline__ uint16_t fw_from_f32(float v) {
+  if constexpr (DT == TS_F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
+  else return __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+
+// Rotary embedding of one 8-element chunk (transformers' apply_rotary_pos_emb, exactly the arithmetic of rope_kernel
+// below: fp32 products and sum each rounded, no fused multiply-add, one rounding to the 16-bit type): `own` holds
+// x[d0 .. d0+8), `par` the partner chunk x[d0 +- DH/2 ...], cs / sn the table entries of the FIRST-half index (the tables
+// repeat: cos[d + DH/2] == cos[d]); second = the chunk lies in the second half.
+template <int DT>
+__device__ __forceinline__ fw_u4 fw_rope8(const fw_u4& own, const fw_u4& par, const float* cs, const float* sn, bool second) {
+#pragma clang fp contract(off)
+  const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4);
+  const float4 s0 = *reinterpret_cast<const float4*>(sn), s1 = *reinterpret_cast<const float4*>(sn + 4);
+  const float cf[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float sf[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  fw_u4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float x = fw_to_f32<DT>((uint16_t)(own[j] >> (16 * k))), xp = fw_to_f32<DT>((uint16_t)(par[j] >> (16 * k)));
+      const float other = second ? xp : -xp;
+      const float rot = (x * cf[2 * j + k]) + (other * sf[2 * j + k]);
+      w |= (uint32_t)fw_from_f32<DT>(rot) << (16 * k);
+    }
+    o[j] = w;
+  }
+  return o;
+}
+
 struct AttnParams {
   const uint16_t* qkv;   // [B, L, 3, heads, DH] 16-bit
   const int32_t* lens;   // [B]
@@ -287,6 +323,7 @@ struct AttnParams {
   int L, heads;
   float scale;
   int window;            // > 0: query q sees key k only if |q - k| <= window (ModernBERT's local layers); 0 = all keys
+  const float *rope_cos, *rope_sin;   // [L, DH] fp32 or null: rotary embedding applied to q and k as they are loaded
 };
 
 // Lanes l and l^32 exchange through v_permlane32_swap: swap(a, b) leaves a = [a.lo32, b.lo32], b = [a.hi32, b.hi32].
@@ -301,7 +338,7 @@ __device__ __forceinline__ float fw_sum_halves(float v) {
 
 #define ATTN_KPAD 8   // K rows in LDS are DH + 8 elements apart: the 16-byte fragment reads of 16 lanes hit 64 distinct banks
 
-template <int DT, int DH>
+template <int DT, int DH, bool ROPE>
 __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int head = blockIdx.x, b = blockIdx.y;
@@ -319,13 +356,57 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   uint16_t* Vt = Ks + (size_t)lp * KS;                             // [DH][vts]
   // ---- the first query tile's loads go out before everything else (see below)
   fw_u4 qnext[DH / 16];
-  {
+  if constexpr (!ROPE) {
     const int qrow = min(wave * 32 + r, len - 1);
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s)
       qnext[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
   }
-  // ---- stage K (row-major) and V (transposed); rows beyond len are zeros.  Four chunks per thread in flight
+  // ---- stage K (row-major) and V (transposed); rows beyond len are zeros
+  if constexpr (ROPE) {
+    // a thread takes a chunk of the first half of a row TOGETHER with its partner in the second half: each is the other's
+    // rotate_half operand.  Two such pairs in flight
+    constexpr int HC = DH / 16;                                    // chunks per half row
+    const int npair = lp * HC;
+    for (int i0 = tid; i0 < npair; i0 += 2 * nthr) {
+      fw_u4 ka[2], kb[2], va[2], vb[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + u * nthr, t = i / HC, c = i % HC;
+        ka[u] = kb[u] = va[u] = vb[u] = fw_u4{0u, 0u, 0u, 0u};
+        if (i < npair && t < len) {
+          const uint16_t* row = base + (int64_t)t * tstride;
+          ka[u] = *reinterpret_cast<const fw_u4*>(row + H + 8 * c);
+          kb[u] = *reinterpret_cast<const fw_u4*>(row + H + DH / 2 + 8 * c);
+          va[u] = *reinterpret_cast<const fw_u4*>(row + 2 * H + 8 * c);
+          vb[u] = *reinterpret_cast<const fw_u4*>(row + 2 * H + DH / 2 + 8 * c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + u * nthr, t = i / HC, c = i % HC;
+        if (i < npair) {
+          fw_u4 ra = ka[u], rb = kb[u];
+          if (t < len) {
+            const float* cs = p.rope_cos + (int64_t)t * DH + 8 * c;
+            const float* sn = p.rope_sin + (int64_t)t * DH + 8 * c;
+            ra = fw_rope8<DT>(ka[u], kb[u], cs, sn, false);
+            rb = fw_rope8<DT>(kb[u], ka[u], cs, sn, true);
+          }
+          *reinterpret_cast<fw_u4*>(Ks + (size_t)t * KS + 8 * c) = ra;
+          *reinterpret_cast<fw_u4*>(Ks + (size_t)t * KS + DH / 2 + 8 * c) = rb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            Vt[(size_t)(8 * c + 2 * j) * vts + t] = (uint16_t)(va[u][j] & 0xffffu);
+            Vt[(size_t)(8 * c + 2 * j + 1) * vts + t] = (uint16_t)(va[u][j] >> 16);
+            Vt[(size_t)(DH / 2 + 8 * c + 2 * j) * vts + t] = (uint16_t)(vb[u][j] & 0xffffu);
+            Vt[(size_t)(DH / 2 + 8 * c + 2 * j + 1) * vts + t] = (uint16_t)(vb[u][j] >> 16);
+          }
+        }
+      }
+    }
+  } else {
+  // Four chunks per thread in flight
   const int nchunk = lp * (DH / 8);
   for (int i0 = tid; i0 < nchunk; i0 += 4 * nthr) {
     fw_u4 kv[4], vv[4];
@@ -351,6 +432,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
       }
     }
   }
+  }
   __syncthreads();
   const float c2 = p.scale * 1.44269504088896341f;                 // softmax in base 2: exp(x*scale - m) = exp2(x*c2 - m2)
 
@@ -359,6 +441,17 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
     // (rows beyond len repeat the last one; never stored.)  The NEXT tile's rows are requested now and used a whole key
     // loop later
     fw_u4 qf[DH / 16];
+    if constexpr (ROPE) {
+      // rotated as they are loaded (own chunk + its partner half a head away); no prefetch of the next tile here
+      const int qrow = min(qt * 32 + r, len - 1);
+      const uint16_t* row = base + (int64_t)qrow * tstride;
+#pragma unroll
+      for (int s = 0; s < DH / 16; ++s) {
+        const int d0 = 16 * s + 8 * h, dp = d0 ^ (DH / 2), dt = d0 & (DH / 2 - 1);
+        const fw_u4 own = *reinterpret_cast<const fw_u4*>(row + d0), par = *reinterpret_cast<const fw_u4*>(row + dp);
+        qf[s] = fw_rope8<DT>(own, par, p.rope_cos + (int64_t)qrow * DH + dt, p.rope_sin + (int64_t)qrow * DH + dt, d0 >= DH / 2);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s) qf[s] = qnext[s];
     if (qt + nwave < ntile) {
@@ -366,6 +459,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
 #pragma unroll
       for (int s = 0; s < DH / 16; ++s)
         qnext[s] = *reinterpret_cast<const fw_u4*>(base + (int64_t)qrow * tstride + 16 * s + 8 * h);
+    }
     }
     float m = -3.0e38f, l = 0.f;                                   // running max (base-2 scaled) and sum of this lane's query
     fw_f16v oacc[DH / 32];
@@ -471,9 +565,9 @@ static size_t attn_lds_bytes(int L, int dh) {
   return ((size_t)lp * (dh + ATTN_KPAD) + (size_t)dh * (lp + 8)) * 2;
 }
 
-template <int DT, int DH>
-static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
-  auto kern = attn_varlen_kernel<DT, DH>;
+template <int DT, int DH, bool ROPE>
+static int launch_attn_t(const AttnParams& p, int B, size_t lds, hipStream_t s) {
+  auto kern = attn_varlen_kernel<DT, DH, ROPE>;
   static TsDeviceOnce lds_attr;
   TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
   // waves per workgroup: each takes query tiles w, w + waves, ...; the fewest waves that keep the number of rounds of
@@ -485,17 +579,24 @@ static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
   TS_HIP(hipGetLastError());
   return TS_OK;
 }
+template <int DT, int DH>
+static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
+  return p.rope_cos ? launch_attn_t<DT, DH, true>(p, B, lds, s) : launch_attn_t<DT, DH, false>(p, B, lds, s);
+}
 
 extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads, int32_t dh,
-                                   int32_t dtype, float scale, int32_t window, void* out, int32_t device, void* stream) {
+                                   int32_t dtype, float scale, int32_t window, const float* rope_cos, const float* rope_sin,
+                                   void* out, int32_t device, void* stream) {
   if (B == 0 || L == 0) return TS_OK;
-  if (!qkv || !lens || !out || B < 0 || L < 0 || heads <= 0 || window < 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
+  if (!qkv || !lens || !out || B < 0 || L < 0 || heads <= 0 || window < 0 || (dtype != TS_F16 && dtype != TS_BF16) ||
+      ((rope_cos == nullptr) != (rope_sin == nullptr))) {
     ts_set_error("bad arguments to attention_varlen");
     return TS_ERR_INVALID;
   }
   const size_t lds = attn_lds_bytes(L, dh);
   if ((dh != 32 && dh != 64) || lds > 160 * 1024 || B > 65535 ||
-      ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) & 15)) {
+      ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(rope_cos) |
+        reinterpret_cast<uintptr_t>(rope_sin)) & 15)) {
     ts_set_error("attention_varlen: head dimension %d / length %d / alignment not supported", dh, L);
     return TS_ERR_UNSUPPORTED;
   }
@@ -504,6 +605,7 @@ extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t
   if (prev != device) TS_HIP(hipSetDevice(device));
   AttnParams p;
   p.qkv = (const uint16_t*)qkv; p.lens = lens; p.out = (uint16_t*)out; p.L = L; p.heads = heads; p.scale = scale; p.window = window;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   int st;
   if (dtype == TS_F16) st = dh == 32 ? launch_attn<TS_F16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_F16, 64>(p, B, lds, (hipStream_t)stream);
   else st = dh == 32 ? launch_attn<TS_BF16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_BF16, 64>(p, B, lds, (hipStream_t)stream);
@@ -519,15 +621,6 @@ extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t
 // rounded, no fused multiply-add — then one rounding to the 16-bit type; gelu(x) = (x * 0.5) * (1 + erf(x / sqrt 2))
 // in fp32 rounded to 16 bit, times the gate rounded again.
 #pragma clang fp contract(off)
-template <int DT> __device__ __forceinline__ float fw_to_f32(uint16_t v) {
-  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, v);
-  else return __uint_as_float((uint32_t)v << 16);
-}
-template <int DT> __device__ __forceinline__ uint16_t fw_from_f32(float v) {
-  if constexpr (DT == TS_F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
-  else return __builtin_bit_cast(uint16_t, (__bf16)v);
-}
-
 template <int DT>
 __global__ __launch_bounds__(256) void rope_kernel(uint16_t* qkv, const float* cosv, const float* sinv, int64_t tokens, int L,
                                                    int heads, int dh) {

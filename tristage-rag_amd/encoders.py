@@ -923,8 +923,8 @@ class LeanModernBertEncoder:
     from the module's own inverse frequencies, global layers and local layers with the bidirectional window
     ``|q - k| <= local_attention / 2``, gated-GELU MLP, final LayerNorm — the arithmetic transformers performs under
     ``torch.autocast`` (linears and attention in the compute dtype, LayerNorms and the residual stream in fp32).  The
-    module launches ~40 small kernels per layer; here a layer is four GEMMs and five HIP kernels (ts_rope_inplace,
-    ts_attention_varlen with its window, ts_add_prenorm twice, ts_geglu).  ``compute_dtype=None``: fp32 torch ops
+    module launches ~40 small kernels per layer; here a layer is four GEMMs and four HIP kernels (ts_attention_varlen
+    with the rotary tables and its window, ts_add_prenorm twice, ts_geglu).  ``compute_dtype=None``: fp32 torch ops
     (tests)."""
 
     def __init__(self, base, compute_dtype=None):
@@ -973,7 +973,7 @@ class LeanModernBertEncoder:
                  and dh in (32, 64) and B <= 65535 and L <= (1120 if dh == 32 else 576))
         lens = None
         if fused:
-            from .index import add_layernorm, attention_varlen, geglu, rope_inplace
+            from .index import add_layernorm, attention_varlen, geglu
             lens = (lengths.to(torch.int32) if lengths is not None
                     else torch.full((B,), L, dtype=torch.int32, device=dev) if attention_mask is None
                     else attention_mask.sum(1, dtype=torch.int32))
@@ -1003,8 +1003,8 @@ class LeanModernBertEncoder:
             qkv = F.linear(xb, *p["qkv"])
             cos, sin = tables[p["type"]]
             if fused:
-                rope_inplace(qkv, cos, sin, nh)
-                a = attention_varlen(qkv, lens, nh, out=abuf, window=self.window if p["type"] == "sliding_attention" else 0)
+                a = attention_varlen(qkv, lens, nh, out=abuf, window=self.window if p["type"] == "sliding_attention" else 0,
+                                     rope=(cos, sin))          # rotary embedding applied as q and k are loaded
             else:
                 q, k, v = (qkv.view(B, L, 3, nh, dh)[:, :, j].transpose(1, 2) for j in range(3))
                 half = lambda z: torch.cat((-z[..., dh // 2:], z[..., : dh // 2]), dim=-1)

@@ -459,10 +459,11 @@ def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32:
     return out32, outlp
 
 
-def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None, window: int = 0):
+def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None, window: int = 0, rope=None):
     """Self-attention of a right-padded batch on the GPU (ts_attention_varlen): ``qkv`` [B, L, 3*heads*dh] (fp16 / bf16,
     the fused projection's output, read in place), ``lens`` int32 [B] on the device.  Returns [B, L, heads*dh]; rows at
-    padded positions are zeros (``out`` given: left as they are).  ``window`` > 0: keys within that distance only."""
+    padded positions are zeros (``out`` given: left as they are).  ``window`` > 0: keys within that distance only.
+    ``rope`` = (cos, sin) float32 [L, dh]: rotary embedding applied to q and k on the fly (qkv is not modified)."""
     torch = _torch()
     lib = _lib.load()
     B, L, W = (int(v) for v in qkv.shape)
@@ -474,8 +475,16 @@ def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = N
     if out is None:
         out = torch.zeros((B, L, heads * dh), dtype=qkv.dtype, device=qkv.device)
     dev = qkv.device.index
+    cos = sin = None
+    if rope is not None:
+        cos, sin = rope
+        for t in (cos, sin):
+            if t.dtype != torch.float32 or tuple(t.shape) != (L, dh) or not t.is_contiguous() or t.device != qkv.device:
+                raise ValueError("rope tables must be contiguous float32 [L, head_dim] on qkv's device")
     _lib.check(lib.ts_attention_varlen(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lens.data_ptr()), B, L, heads, dh,
                                        _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5), int(window),
+                                       ctypes.c_void_p(cos.data_ptr()) if cos is not None else None,
+                                       ctypes.c_void_p(sin.data_ptr()) if sin is not None else None,
                                        ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out
 
