@@ -193,7 +193,7 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument("--mode", choices=["rerank", "dense"], default="rerank")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-bm25", action="store_true", help="stage1_enable_bm25=False (pure dense stage 1)")
-    ap.add_argument("--token-store", action="store_true", help="stage-2 token matrices resident on the GPU")
+    ap.add_argument("--token-store", action="store_true", help="stage-2 token matrices and stage-3 token ids resident (search_many on arrays)")
     ap.add_argument("--index-dtype", default="f32", choices=["f32", "f16", "bf16"])
     args = ap.parse_args(argv)
     logging.basicConfig(level=getattr(logging, args.log_level),
@@ -208,6 +208,7 @@ def main(argv: Optional[List[str]] = None) -> int:
         overrides["stage1_enable_bm25"] = False
     if args.token_store:
         overrides["stage2_precompute_document_embeddings"] = True
+        overrides["stage3_cache_document_tokens"] = True      # with the token store: every stage of search_many on arrays
     if args.index_dtype != "f32":
         overrides["stage1_index_dtype"] = args.index_dtype
     if args.log_level != "INFO":
