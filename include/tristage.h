@@ -26,7 +26,9 @@
  *     submitting thread per handle at a time; synchronous searches from other
  *     threads may run beside it.  add / reset / reserve / set_id_offset /
  *     destroy need exclusive access.  The stateless entry points (ts_merge_topk*,
- *     ts_maxsim*) are thread-safe; per-kernel device attributes are set once per
+ *     ts_maxsim*, and the forward kernels ts_add_layernorm / ts_add_prenorm /
+ *     ts_embed_layernorm / ts_attention_varlen / ts_rope_inplace / ts_geglu) are
+ *     thread-safe; a ts_bm25 handle serves one caller at a time; per-kernel device attributes are set once per
  *     device under a lock, so one process may drive several GPUs.
  */
 #ifndef TRISTAGE_H_
@@ -219,7 +221,9 @@ int ts_maxsim_indexed_batch(const void* q, const int32_t* q_off, int32_t nq, con
  * by term, idf[V], len_norm[N] = k1*(1-b+b*len/avg), k1p1 = k1+1.
  * ts_bm25_search: term_ids = query tokens as vocabulary ids in query order (host);
  * writes up to k (score, doc) pairs to HOST arrays; *n_out < k means all documents
- * with a non-zero score were returned (the rest score exactly 0.0).            */
+ * with a non-zero score were returned (the rest score exactly 0.0).  A ts_bm25
+ * handle keeps ONE accumulator / candidate workspace: calls on one handle must not
+ * overlap (one caller at a time; different handles are independent).            */
 typedef struct ts_bm25 ts_bm25;
 int ts_bm25_create(int32_t device, ts_bm25** out);
 int ts_bm25_destroy(ts_bm25* h);
