@@ -82,6 +82,8 @@ class BM25Index:
         self.b = b
         self.gpu_device = gpu_device   # None: score on the host; int: HIP kernels on that GPU
         self._gpu = None
+        import threading
+        self._gpu_lock = threading.Lock()   # the GPU handle serves one caller at a time
         self._term_id: Dict[str, int] = {}
         self.doc_freqs: List[Dict[str, int]] = []
         self.idf: Dict[str, float] = {}
@@ -171,8 +173,9 @@ class BM25Index:
         out_i = np.zeros((nq, max(k, 1)), dtype=np.int64)
         n_out = np.zeros(max(nq, 1), dtype=np.int32)
         if k > 0 and nq and off[-1]:
-            _lib.check(lib.ts_bm25_search_batch(self._gpu, flat.ctypes.data, off.ctypes.data, nq, k, out_s.ctypes.data,
-                                                out_i.ctypes.data, n_out.ctypes.data, None))
+            with self._gpu_lock:      # one accumulator per handle, and ctypes drops the GIL for the call
+                _lib.check(lib.ts_bm25_search_batch(self._gpu, flat.ctypes.data, off.ctypes.data, nq, k, out_s.ctypes.data,
+                                                    out_i.ctypes.data, n_out.ctypes.data, None))
         if arrays:      # (ids, scores) per query, no tuples: the array path of Stage1Retriever fuses them as they are
             want = min(int(top_k), self.corpus_size)
             out = []
