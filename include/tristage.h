@@ -287,11 +287,14 @@ int ts_embed_layernorm(const int64_t* ids, const int64_t* pos_ids, const int64_t
  * window = local_attention / 2); 0 = all keys.  rope_cos / rope_sin (fp32 [L, dh], both or
  * neither): the rotary embedding of ts_rope_inplace applied to q and k as they are
  * loaded — same arithmetic, same results as ts_rope_inplace followed by this call
- * without tables, minus one pass over q and k (qkv itself is left as it is).         */
+ * without tables, minus one pass over q and k (qkv itself is left as it is).
+ * offs (int32 [B] on the device, or NULL): a PACKED batch — qkv is [T, 3, heads, dh] and out
+ * [T, heads*dh] with sequence b occupying tokens offs[b] .. offs[b] + lens[b]; L is then
+ * only the upper bound of lens (it sizes the LDS tiles).  NULL: the padded layout above.  */
 int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads,
                         int32_t dh, int32_t dtype, float scale, int32_t window,
-                        const float* rope_cos, const float* rope_sin, void* out, int32_t device,
-                        void* stream);
+                        const float* rope_cos, const float* rope_sin, const int32_t* offs, void* out,
+                        int32_t device, void* stream);
 
 /* Rotary position embedding of the q and k thirds of qkv [B, L, 3, heads, dh] in place:
  * x <- x * cos + rotate_half(x) * sin with fp32 tables cos / sin [L, dh] (row = token

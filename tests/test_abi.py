@@ -114,15 +114,15 @@ def test_forward_kernel_entry_points_validate_arguments_without_a_gpu():
     assert lib.ts_embed_layernorm(p, p, None, p, p, p, p, None, f, 4, 62, p, None, BF, 0, None) == _lib.TS_ERR_UNSUPPORTED
     assert lib.ts_embed_layernorm(p, p, None, p, p, p, p, None, f, 0, 64, p, None, BF, 0, None) == _lib.TS_OK
     one = ctypes.c_float(0.125)
-    assert lib.ts_attention_varlen(None, p, 2, 64, 4, 32, BF, one, 0, None, None, p, 0, None) == _lib.TS_ERR_INVALID
-    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, F32, one, 0, None, None, p, 0, None) == _lib.TS_ERR_INVALID     # 16-bit types only
-    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, BF, one, -1, None, None, p, 0, None) == _lib.TS_ERR_INVALID     # negative window
-    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 48, BF, one, 0, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # head dimension
-    assert lib.ts_attention_varlen(p, p, 2, 4096, 4, 64, BF, one, 0, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # K, V^T beyond LDS
-    assert lib.ts_attention_varlen(p, p, 70000, 64, 4, 32, BF, one, 0, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # grid limit
+    assert lib.ts_attention_varlen(None, p, 2, 64, 4, 32, BF, one, 0, None, None, None, p, 0, None) == _lib.TS_ERR_INVALID
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, F32, one, 0, None, None, None, p, 0, None) == _lib.TS_ERR_INVALID     # 16-bit types only
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, BF, one, -1, None, None, None, p, 0, None) == _lib.TS_ERR_INVALID     # negative window
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 48, BF, one, 0, None, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # head dimension
+    assert lib.ts_attention_varlen(p, p, 2, 4096, 4, 64, BF, one, 0, None, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # K, V^T beyond LDS
+    assert lib.ts_attention_varlen(p, p, 70000, 64, 4, 32, BF, one, 0, None, None, None, p, 0, None) == _lib.TS_ERR_UNSUPPORTED  # grid limit
     assert b"attention_varlen" in lib.ts_last_error()
-    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, BF, one, 0, p, None, p, 0, None) == _lib.TS_ERR_INVALID    # cos without sin
-    assert lib.ts_attention_varlen(p, p, 0, 64, 4, 32, BF, one, 0, None, None, p, 0, None) == _lib.TS_OK
+    assert lib.ts_attention_varlen(p, p, 2, 64, 4, 32, BF, one, 0, p, None, None, p, 0, None) == _lib.TS_ERR_INVALID    # cos without sin
+    assert lib.ts_attention_varlen(p, p, 0, 64, 4, 32, BF, one, 0, None, None, None, p, 0, None) == _lib.TS_OK
     assert lib.ts_rope_inplace(None, BF, p, p, 2, 64, 4, 32, 0, None) == _lib.TS_ERR_INVALID
     assert lib.ts_rope_inplace(p, F32, p, p, 2, 64, 4, 32, 0, None) == _lib.TS_ERR_INVALID
     assert lib.ts_rope_inplace(p, BF, p, p, 2, 64, 4, 36, 0, None) == _lib.TS_ERR_UNSUPPORTED

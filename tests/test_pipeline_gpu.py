@@ -585,3 +585,58 @@ def test_amp_dtype_option_runs_the_forwards_and_the_token_store_in_that_type(tmp
         assert len(set(ia) & set(ib)) >= 6, (amp, ia, ib)                 # 16-bit forwards of random-init models vs fp32
     with pytest.raises(ValueError):
         build("bad", amp_dtype="fp8")
+
+
+def test_packed_batches_equal_padded_batches():
+    """PACKED batches (the sequences' tokens concatenated; ts_attention_varlen with offsets, LayerNorm / GEMMs / GELU on
+    sum(lengths) rows): the attention kernel gives bit for bit what it gives on the padded layout, PairAssembler's
+    packed ids are the padded ids without their padding, and the classifier's logits agree with the padded forward's
+    (other GEMM row counts: bf16 accumulation-order noise) and with the transformers module under autocast."""
+    import torch
+    from tristage_rag_amd.encoders import CrossEncoderModel, PairAssembler
+    from tristage_rag_amd.index import attention_varlen
+    g = torch.Generator(device="cuda").manual_seed(23)
+    B, L, nh, dh = 9, 150, 3, 32
+    H = nh * dh
+    lens = torch.tensor([L, 1, 33, 64, 150, 17, 96, 2, 128], dtype=torch.int32, device="cuda")
+    qkv = torch.randn((B, L, 3 * H), generator=g, device="cuda").to(torch.bfloat16)
+    valid = torch.arange(L, device="cuda")[None, :] < lens[:, None]
+    offs = (torch.cumsum(lens, 0) - lens).to(torch.int32)
+    padded = attention_varlen(qkv, lens, nh)
+    packed = attention_varlen(qkv[valid].contiguous(), lens, nh, offs=offs, max_len=L)
+    assert packed.shape == (int(lens.sum()), H) and torch.equal(packed, padded[valid])
+    for window in (0, 20):
+        ang = torch.rand((L, dh // 2), generator=g, device="cuda") * 6.28
+        cos, sin = torch.cat((ang.cos(), ang.cos()), -1).contiguous(), torch.cat((ang.sin(), ang.sin()), -1).contiguous()
+        a = attention_varlen(qkv, lens, nh, window=window, rope=(cos, sin))
+        b = attention_varlen(qkv[valid].contiguous(), lens, nh, window=window, rope=(cos, sin), offs=offs, max_len=L)
+        assert torch.equal(b, a[valid])
+    with pytest.raises(ValueError):
+        attention_varlen(qkv[valid].contiguous(), lens, nh, offs=offs)                 # max_len missing
+    # the assembled pairs
+    docs = _corpus(400)
+    queries = ["neural network attention", "gpu memory index retrieval system", "token"]
+    for spec in ("random:minilm", "random:xlmr-large:64:2:2"):
+        ce = CrossEncoderModel(spec, device="cuda", use_amp=True)
+        pa = PairAssembler(ce.tokenizer, 64)
+        pa.add_documents(docs)
+        n = 500
+        pq = torch.randint(0, 3, (n,), generator=g, device="cuda")
+        pd = torch.randint(0, len(docs), (n,), generator=g, device="cuda")
+        plan = pa.plan([pa.ids_of(q) for q in queries], pq, pd, "cuda")
+        sel = torch.arange(n, device="cuda")
+        width = int(plan["total"].max())
+        enc = pa.batch(plan, sel, width=width)
+        pk = pa.batch_packed(plan, sel, int(plan["total"].sum()), width)
+        m = enc["attention_mask"].bool()
+        assert torch.equal(pk["input_ids"], enc["input_ids"][m]) and torch.equal(pk["lengths"], enc["lengths"])
+        if pk["token_type_ids"] is not None:
+            assert torch.equal(pk["token_type_ids"], enc["token_type_ids"][m])
+        assert torch.equal(pk["positions"], torch.arange(width, device="cuda")[None, :].expand(n, width)[m])
+        assert ce.packed_ok(width, n)
+        a = ce.logits_from_ids(enc)
+        b = ce.logits_from_ids(pk)
+        assert a.shape == b.shape and float((a - b).abs().max()) < 4e-3
+        ce.lean_forward = False
+        ref = ce.logits_from_ids(enc)
+        assert float((b - ref).abs().max()) < 4e-3

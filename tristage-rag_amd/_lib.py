@@ -66,7 +66,7 @@ SIGNATURES = {
     "ts_add_prenorm": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int32, c_void_p,
                                  c_void_p, c_int32, c_int32, c_void_p]),
     "ts_attention_varlen": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32,
-                                      c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ts_rope_inplace": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ts_geglu": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
     "ts_maxsim_release_scratch": (c_int32, [c_int32]),

@@ -324,6 +324,8 @@ struct AttnParams {
   float scale;
   int window;            // > 0: query q sees key k only if |q - k| <= window (ModernBERT's local layers); 0 = all keys
   const float *rope_cos, *rope_sin;   // [L, DH] fp32 or null: rotary embedding applied to q and k as they are loaded
+  const int32_t* offs;   // [B] or null: sequence b starts at token offs[b] of a PACKED batch (qkv [T, 3, heads, DH], out [T, H]);
+                         // null: the padded layout, sequence b starts at token b * L
 };
 
 // Lanes l and l^32 exchange through v_permlane32_swap: swap(a, b) leaves a = [a.lo32, b.lo32], b = [a.hi32, b.hi32].
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
   const int H = p.heads * DH;
   constexpr int KS = DH + ATTN_KPAD;
   const int64_t tstride = 3 * (int64_t)H;                          // elements between consecutive tokens
-  const uint16_t* base = p.qkv + (int64_t)b * p.L * tstride + head * DH;
+  const int64_t tok0 = p.offs ? (int64_t)p.offs[b] : (int64_t)b * p.L;     // first token of this sequence
+  const uint16_t* base = p.qkv + tok0 * tstride + head * DH;
   const int ntile = (len + 31) >> 5, lp = ntile * 32;
   const int vts = lp + 8;                                          // row stride of V^T (elements): +8 against bank conflicts
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);                // [lp][KS]
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnParams p) {
     const int q = qt * 32 + r;
     if (q < len) {
       const float inv = 1.0f / l;
-      uint16_t* orow = p.out + ((int64_t)b * p.L + q) * H + head * DH;
+      uint16_t* orow = p.out + (tok0 + q) * H + head * DH;
 #pragma unroll
       for (int d = 0; d < DH / 32; ++d)
 #pragma unroll
@@ -586,7 +589,7 @@ static int launch_attn(const AttnParams& p, int B, size_t lds, hipStream_t s) {
 
 extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t B, int32_t L, int32_t heads, int32_t dh,
                                    int32_t dtype, float scale, int32_t window, const float* rope_cos, const float* rope_sin,
-                                   void* out, int32_t device, void* stream) {
+                                   const int32_t* offs, void* out, int32_t device, void* stream) {
   if (B == 0 || L == 0) return TS_OK;
   if (!qkv || !lens || !out || B < 0 || L < 0 || heads <= 0 || window < 0 || (dtype != TS_F16 && dtype != TS_BF16) ||
       ((rope_cos == nullptr) != (rope_sin == nullptr))) {
@@ -605,7 +608,7 @@ extern "C" int ts_attention_varlen(const void* qkv, const int32_t* lens, int32_t
   if (prev != device) TS_HIP(hipSetDevice(device));
   AttnParams p;
   p.qkv = (const uint16_t*)qkv; p.lens = lens; p.out = (uint16_t*)out; p.L = L; p.heads = heads; p.scale = scale; p.window = window;
-  p.rope_cos = rope_cos; p.rope_sin = rope_sin;
+  p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.offs = offs;
   int st;
   if (dtype == TS_F16) st = dh == 32 ? launch_attn<TS_F16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_F16, 64>(p, B, lds, (hipStream_t)stream);
   else st = dh == 32 ? launch_attn<TS_BF16, 32>(p, B, lds, (hipStream_t)stream) : launch_attn<TS_BF16, 64>(p, B, lds, (hipStream_t)stream);

@@ -459,33 +459,45 @@ def add_layernorm(x, residual, gamma, beta, eps: float, lp_dtype=None, want_f32:
     return out32, outlp
 
 
-def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None, window: int = 0, rope=None):
+def attention_varlen(qkv, lens, heads: int, out=None, scale: Optional[float] = None, window: int = 0, rope=None,
+                     offs=None, max_len: Optional[int] = None):
     """Self-attention of a right-padded batch on the GPU (ts_attention_varlen): ``qkv`` [B, L, 3*heads*dh] (fp16 / bf16,
     the fused projection's output, read in place), ``lens`` int32 [B] on the device.  Returns [B, L, heads*dh]; rows at
     padded positions are zeros (``out`` given: left as they are).  ``window`` > 0: keys within that distance only.
-    ``rope`` = (cos, sin) float32 [L, dh]: rotary embedding applied to q and k on the fly (qkv is not modified)."""
+    ``rope`` = (cos, sin) float32 [L, dh]: rotary embedding applied to q and k on the fly (qkv is not modified).
+    PACKED batches: ``qkv`` [T, 3*heads*dh] with ``offs`` int32 [B] (first token of each sequence, on the device) and
+    ``max_len`` >= every length; returns [T, heads*dh]."""
     torch = _torch()
     lib = _lib.load()
-    B, L, W = (int(v) for v in qkv.shape)
+    packed = offs is not None
+    if packed:
+        if qkv.dim() != 2 or max_len is None:
+            raise ValueError("a packed batch is qkv [T, 3 * heads * head_dim] with offs and max_len")
+        T, W = (int(v) for v in qkv.shape)
+        B, L = int(lens.numel()), int(max_len)
+        if offs.dtype != torch.int32 or offs.numel() != B or offs.device != qkv.device:
+            raise ValueError("offs must be int32 [B] on qkv's device")
+    else:
+        B, L, W = (int(v) for v in qkv.shape)
     if W % (3 * heads):
         raise ValueError("last dimension must be 3 * heads * head_dim")
     dh = W // (3 * heads)
     if not qkv.is_contiguous() or lens.dtype != torch.int32 or lens.numel() != B or lens.device != qkv.device:
         raise ValueError("qkv must be contiguous and lens int32 [B] on the same device")
     if out is None:
-        out = torch.zeros((B, L, heads * dh), dtype=qkv.dtype, device=qkv.device)
+        out = torch.zeros(((T,) if packed else (B, L)) + (heads * dh,), dtype=qkv.dtype, device=qkv.device)
     dev = qkv.device.index
     cos = sin = None
     if rope is not None:
         cos, sin = rope
         for t in (cos, sin):
-            if t.dtype != torch.float32 or tuple(t.shape) != (L, dh) or not t.is_contiguous() or t.device != qkv.device:
-                raise ValueError("rope tables must be contiguous float32 [L, head_dim] on qkv's device")
-    _lib.check(lib.ts_attention_varlen(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lens.data_ptr()), B, L, heads, dh,
-                                       _tensor_dtype(qkv), float(scale if scale is not None else dh ** -0.5), int(window),
-                                       ctypes.c_void_p(cos.data_ptr()) if cos is not None else None,
-                                       ctypes.c_void_p(sin.data_ptr()) if sin is not None else None,
-                                       ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+            if (t.dtype != torch.float32 or t.dim() != 2 or t.shape[0] < L or t.shape[1] != dh or not t.is_contiguous()
+                    or t.device != qkv.device):
+                raise ValueError("rope tables must be contiguous float32 [>= L, head_dim] on qkv's device")
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(lib.ts_attention_varlen(ptr(qkv), ptr(lens), B, L, heads, dh, _tensor_dtype(qkv),
+                                       float(scale if scale is not None else dh ** -0.5), int(window), ptr(cos), ptr(sin),
+                                       ptr(offs), ptr(out), dev, ctypes.c_void_p(_stream_ptr(dev))))
     return out
 
 

@@ -37,6 +37,8 @@ class Stage3Config:
     many_batch_size: int = 1024  # pairs per forward when several queries are reranked together (rerank_many)
     amp_dtype: str = "bf16"      # what use_fp16 means on the GPU: "bf16" or "fp16" (the reference's autocast)
     many_width_multiple: int = 1  # rerank_arrays pads the token width of a batch to a multiple of this (fewer GEMM shapes)
+    many_packed: bool = True      # rerank_arrays runs PACKED batches (the pairs' tokens concatenated, no padded position
+                                  # computed) when the written-out forward with its HIP kernels is in use
 
 
 class CrossEncoderReranker:
@@ -223,12 +225,25 @@ class CrossEncoderReranker:
         order = torch.argsort(plan["total"], descending=True, stable=True)
         raw = torch.empty((B * C,), dtype=torch.float32, device=dev)
         bs = max(self.config.batch_size, self.config.many_batch_size)
-        widths = plan["total"][order[::bs]].tolist()          # one host sync: the padded width of every batch
+        tot = plan["total"][order]
+        csum = torch.cumsum(tot, 0)
+        ends = torch.arange(bs, B * C + bs, bs, device=dev).clamp(max=B * C) - 1
+        host = torch.stack([tot[::bs], csum[ends]]).tolist()      # one host sync: every batch's padded width and token count
+        widths = host[0]
+        tokens = [int(e - s) for e, s in zip(host[1], [0] + host[1][:-1])]
         wm = max(int(getattr(self.config, "many_width_multiple", 1) or 1), 1)
         if wm > 1:                                            # (padding is masked: same scores up to batch-padding noise)
             widths = [min(-(-int(w) // wm) * wm, max(int(self.config.max_length), int(w))) for w in widths]
+        # packed batches (no padded position in the GEMMs, LayerNorms or GELU) whenever the written-out forward takes them
+        graph_one = B * C <= bs and getattr(self.model, "use_hip_graph", False)    # one query's pairs: the replayed graph wins
+        packed = (wm == 1 and not graph_one and getattr(self.config, "many_packed", True) and hasattr(self.model, "packed_ok")
+                  and self.model.packed_ok(int(max(widths)), min(bs, B * C)))
         for j, s in enumerate(range(0, B * C, bs)):
             sel = order[s: s + bs]
+            if packed:
+                enc = pa.batch_packed(plan, sel, tokens[j], int(widths[j]))
+                raw[sel] = self.model.activate(self.model.logits_from_ids(enc)).reshape(-1)
+                continue
             enc = pa.batch(plan, sel, width=int(widths[j]))
             lg = self.model.logits_graphed(enc) if B * C <= bs else None   # one query's pairs: graph replay if enabled
             raw[sel] = self.model.activate(lg if lg is not None else self.model.logits_from_ids(enc)).reshape(-1)
