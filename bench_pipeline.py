@@ -121,6 +121,7 @@ def main():
                    "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
                    "queries_per_search_many": args.many, "bm25_rrf": args.bm25,
                    "stage3_token_id_cache": args.ids, "stage3_pairs_per_forward": args.s3_batch,
+                   "stage3_pairs_per_packed_forward": int(getattr(p.stage3.config, "many_packed_batch_size", args.s3_batch)),
                    "stage3_lean_forward": bool(getattr(p.stage3.model, "_lean", None)), "save_intermediate_results": args.keep,
                    "array_path": bool(args.ids and args.store and getattr(p.stage3, "_pairs_usable", False)
                                       and (args.many or p.config.search_on_arrays))},

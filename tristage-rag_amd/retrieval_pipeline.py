@@ -84,6 +84,7 @@ class PipelineConfig:
     stage3_cache_document_tokens: bool = False  # tokenise every document once at add time; search_many then assembles
                                                 # the cross-encoder inputs from token ids on the GPU
     stage3_many_batch_size: int = 1024       # pairs per cross-encoder forward in search_many
+    stage3_many_packed_batch_size: int = 4096  # ... when the batch is packed (written-out forward on the GPU): no padding to pay
 
 
 # (section, key) in the reference's YAML layout -> PipelineConfig field (reference :182-217)
@@ -192,7 +193,8 @@ class RetrievalPipeline:
                 max_length=c.stage3_max_length, batch_size=c.stage3_batch_size,
                 top_k_final=c.stage3_top_k, use_fp16=c.stage3_use_fp16, use_hip_graph=c.use_hip_graphs,
                 many_batch_size=c.stage3_many_batch_size, amp_dtype=c.amp_dtype,
-                many_width_multiple=c.stage3_width_multiple))
+                many_width_multiple=c.stage3_width_multiple,
+                many_packed_batch_size=max(c.stage3_many_batch_size, c.stage3_many_packed_batch_size)))
             self.logger.info("Stage 3 initialized")
         except Exception as e:
             self.logger.error(f"Error initializing pipeline stages: {e}")
