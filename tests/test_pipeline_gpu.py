@@ -640,3 +640,26 @@ def test_packed_batches_equal_padded_batches():
         ce.lean_forward = False
         ref = ce.logits_from_ids(enc)
         assert float((b - ref).abs().max()) < 4e-3
+
+
+def test_rrf_fusion_on_the_gpu_is_bit_identical_to_the_host_code():
+    """Stage1Retriever._fuse_rrf_device (one stable float64 sort for a whole query batch) against _fuse_arrays per query
+    (itself pinned to the reference's dictionary code on the CPU): same ids, same float64 scores, same tie order —
+    overlapping, disjoint and identical dense / BM25 lists."""
+    import torch
+    from tristage_rag_amd.stage1_retriever import Stage1Config, Stage1Retriever
+    s1 = object.__new__(Stage1Retriever)
+    s1.config = Stage1Config()
+    rng = np.random.default_rng(8)
+    for k1, k2, top_k, universe in ((1000, 300, 1000, 3633), (50, 50, 50, 60), (200, 300, 120, 100000), (64, 10, 64, 64)):
+        B = 17
+        dense = np.stack([rng.permutation(universe)[:k1] for _ in range(B)]).astype(np.int64)
+        bm = np.stack([rng.permutation(universe)[:k2] for _ in range(B)]).astype(np.int64)
+        bm[0, : min(k1, k2)] = dense[0, : min(k1, k2)]                        # identical prefixes
+        dscores = np.sort(rng.random((B, k1)).astype(np.float32), axis=1)[:, ::-1].copy()
+        gi, gs = s1._fuse_rrf_device(torch.from_numpy(dense).cuda(), bm, top_k)
+        assert gi.dtype == torch.int64 and gs.dtype == torch.float64 and gi.shape == (B, top_k)
+        gi, gs = gi.cpu().numpy(), gs.cpu().numpy()
+        for q in range(B):
+            hi, hs = s1._fuse_arrays(dense[q], dscores[q], (bm[q], np.ones(k2)))
+            assert np.array_equal(gi[q], hi[:top_k]) and np.array_equal(gs[q], hs[:top_k])

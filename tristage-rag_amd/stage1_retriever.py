@@ -42,6 +42,8 @@ class Stage1Config:
     top_k_candidates: int = 500
     batch_size: int = 32
     index_batch_size: int = 256     # additive: documents per encoder forward in add_documents on the device path
+    fuse_on_gpu: bool = True        # additive: search_many's RRF fusion for the whole query batch on the GPU (same float64
+                                    # arithmetic and tie order as the per-query host code)
     amp_dtype: str = "bf16"         # additive: what use_fp16 means on the GPU — "bf16" (BASELINE configs[2]) or "fp16"
                                     # (what torch.cuda.amp.autocast() gives the reference, :235)
     max_text_length: int = 512
@@ -487,10 +489,16 @@ class Stage1Retriever:
             D, I = torch.as_tensor(D), torch.as_tensor(I)
         if not (self.config.enable_bm25 and self.bm25_index is not None):
             return I, D
+        bm25 = self.bm25_index
+        if (self.config.fusion_method == "rrf" and I.is_cuda and getattr(self.config, "fuse_on_gpu", True)
+                and hasattr(bm25, "search_many_arrays")):
+            bms = bm25.search_many_arrays(list(queries), self.config.bm25_top_k)
+            k2 = len(bms[0][0]) if bms else 0
+            if k2 > 0 and all(len(b[0]) == k2 for b in bms):      # (ragged BM25 lists: the per-query host code below)
+                return self._fuse_rrf_device(I, np.stack([b[0] for b in bms]), top_k)
         ids, scores = I.cpu().numpy(), D.cpu().numpy()
         out_i = np.empty((len(queries), top_k), dtype=np.int64)
         out_s = np.empty((len(queries), top_k), dtype=np.float64)
-        bm25 = self.bm25_index
         bms = (bm25.search_many_arrays(list(queries), self.config.bm25_top_k) if hasattr(bm25, "search_many_arrays")
                else [bm25.search(q, self.config.bm25_top_k) for q in queries])
         for qi, bm in enumerate(bms):
@@ -499,6 +507,33 @@ class Stage1Retriever:
                 return None
             out_i[qi], out_s[qi] = fi[:top_k], fs[:top_k]
         return out_i, out_s
+
+    def _fuse_rrf_device(self, dense_ids, bm25_ids: np.ndarray, top_k: int):
+        """Reciprocal rank fusion of a whole query batch on the GPU: dense_ids int64 [B, k1] (device, rank order), bm25_ids
+        int64 [B, k2] (host, rank order) -> (ids int64 [B, top_k], fused scores float64 [B, top_k]) on the device.  The
+        arithmetic of _fuse_arrays / _reciprocal_rank_fusion (reference :326-340) in float64 — 1 / (k + rank + 1), the
+        dense term first, then the BM25 term — and its order: descending fused score, ties in first-seen order (dense
+        list, then the BM25-only documents in BM25 order), by ONE stable sort per batch; bit-identical to the host code
+        (tested)."""
+        import torch
+        dev = dense_ids.device
+        B, k1 = dense_ids.shape
+        b_ids = torch.from_numpy(np.ascontiguousarray(bm25_ids)).to(dev)
+        k2 = int(b_ids.shape[1])
+        rk = float(self.config.rrf_k)
+        d_part = 1.0 / (rk + torch.arange(k1, dtype=torch.float64, device=dev) + 1)
+        b_part = 1.0 / (rk + torch.arange(k2, dtype=torch.float64, device=dev) + 1)
+        sorted_ids, order = torch.sort(dense_ids, dim=1, stable=True)
+        pos = torch.searchsorted(sorted_ids, b_ids).clamp(max=k1 - 1)
+        hit = torch.gather(sorted_ids, 1, pos) == b_ids                       # the BM25 document is in the dense list
+        where = torch.gather(order, 1, pos)                                   # ... at this rank
+        fused = d_part.expand(B, k1).clone()
+        fused.scatter_add_(1, where, torch.where(hit, b_part.expand(B, k2), torch.zeros((), dtype=torch.float64, device=dev)))
+        all_ids = torch.cat([dense_ids, b_ids], dim=1)
+        minus_inf = torch.full((), float("-inf"), dtype=torch.float64, device=dev)
+        all_sc = torch.cat([fused, torch.where(hit, minus_inf, 0.0 + b_part.expand(B, k2))], dim=1)
+        srt, rank = torch.sort(all_sc, dim=1, descending=True, stable=True)
+        return torch.gather(all_ids, 1, rank[:, :top_k]).contiguous(), srt[:, :top_k].contiguous()
 
     def _fuse_arrays(self, dense_ids: np.ndarray, dense_scores: np.ndarray, bm25_results):
         """The fusion of _finish() on arrays: same float64 arithmetic, same order (descending fused score,
