@@ -232,7 +232,10 @@ def to_device_async(t: torch.Tensor, device) -> torch.Tensor:
     tokenising and launching with the GPU's work.  (torch's pinned-memory cache keeps the staging buffer alive until
     the copy has run.)  Anything that is not a CPU tensor, or a non-GPU target, takes the ordinary path."""
     if isinstance(t, torch.Tensor) and not t.is_cuda and str(device).startswith("cuda"):
-        return t.pin_memory().to(device, non_blocking=True)
+        try:
+            return t.pin_memory().to(device, non_blocking=True)
+        except RuntimeError:          # no pinned memory to be had: the blocking copy
+            pass
     return t.to(device)
 
 
