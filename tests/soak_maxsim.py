@@ -1,6 +1,6 @@
-# one-off randomized soak of the streaming MaxSim against the oracle (not part of the suite)
+# one-off randomized soak of the streaming MaxSim against the oracle (run by hand: python tests/soak_maxsim.py SEED; not collected by pytest)
 import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from oracle import oracle
 from tristage_rag_amd.index import maxsim_indexed, maxsim_indexed_batch, maxsim
