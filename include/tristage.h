@@ -27,7 +27,8 @@
  *     threads may run beside it.  add / reset / reserve / set_id_offset /
  *     destroy need exclusive access.  The stateless entry points (ts_merge_topk*,
  *     ts_maxsim*, and the forward kernels ts_add_layernorm / ts_add_prenorm /
- *     ts_embed_layernorm / ts_attention_varlen / ts_rope_inplace / ts_geglu) are
+ *     ts_embed_layernorm / ts_attention_varlen / ts_rope_inplace / ts_geglu /
+ *     ts_linear_*) are
  *     thread-safe; a ts_bm25 handle serves one caller at a time; per-kernel device attributes are set once per
  *     device under a lock, so one process may drive several GPUs.
  */
@@ -308,6 +309,23 @@ int ts_rope_inplace(void* qkv, int32_t dtype, const float* cos_tab, const float*
  * roundings of the two torch ops).  I a multiple of 8.                               */
 int ts_geglu(const void* u, int32_t dtype, int64_t rows, int32_t I, void* out, int32_t device,
              void* stream);
+
+/* ---- linear layers with a short reduction dimension (the projections of those forwards) ---
+ * out[M, N] = act(x[M, K] w[N, K]^T + bias[N]) for the Q/K/V, attention-output and feed-
+ * forward "up" projections of MiniLM / BERT-base sized encoders (K <= 768 is where it beats
+ * the library GEMM; any K that is a multiple of 128 up to 2560 is accepted), act 0 = none,
+ * 1 = erf GELU (BertIntermediate: no separate activation pass over the M x N result).
+ * The weight is re-tiled ONCE with ts_linear_tile_weight (w [N, K] in torch.nn.Linear
+ * layout -> out, N*K elements of the same dtype) and then streamed from L2 by every
+ * workgroup while the workgroup's rows of x sit in LDS (the structure of the stage-1 scan,
+ * DESIGN.md 4.7).  x, bias (may be NULL), out of dtype (TS_F16 / TS_BF16), fp32 accumulation;
+ * sum + bias is rounded to dtype before the activation, the result rounded again — the
+ * roundings of linear followed by gelu.  N a multiple of 32; pointers 16-byte aligned
+ * (bias 8).                                                                              */
+int ts_linear_tile_weight(const void* w, int32_t dtype, int32_t N, int32_t K, void* out,
+                          int32_t device, void* stream);
+int ts_linear_act(const void* w_tiled, const void* x, const void* bias, int32_t dtype, int64_t M,
+                  int32_t N, int32_t K, int32_t act, void* out, int32_t device, void* stream);
 
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */

@@ -663,3 +663,36 @@ def test_rrf_fusion_on_the_gpu_is_bit_identical_to_the_host_code():
         for q in range(B):
             hi, hs = s1._fuse_arrays(dense[q], dscores[q], (bm[q], np.ones(k2)))
             assert np.array_equal(gi[q], hi[:top_k]) and np.array_equal(gs[q], hs[:top_k])
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_tiled_linear_matches_torch(dt):
+    """index.TiledLinear (ts_linear_tile_weight + ts_linear_act: the weight streamed from L2, the rows of x in LDS) against
+    F.linear and F.gelu(F.linear): within one 16-bit step of the result (accumulation order, and the erf of the GELU
+    epilogue is a 1.5e-7 approximation), ragged row counts, with and without bias, the shapes of the encoders."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import TiledLinear
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    step = 2.0 ** (-8 if dt == "bf16" else -11)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    for M, K, N in ((5000, 384, 1152), (4097, 384, 384), (1, 384, 1536), (777, 768, 3072), (100, 768, 768), (300, 128, 32)):
+        x = (torch.randn((M, K), generator=g, device="cuda") * 0.8).to(tdt)
+        w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(tdt)
+        b = (torch.randn((N,), generator=g, device="cuda") * 0.1).to(tdt)
+        for bias in (b, None):
+            lin = TiledLinear(w, bias)
+            ref = F.linear(x, w, bias)
+            got = lin(x)
+            assert got.shape == ref.shape and got.dtype == tdt
+            assert float((got.float() - ref.float()).abs().max()) <= 2 * step * max(1.0, float(ref.abs().max()))
+            refg = F.gelu(ref)
+            gotg = lin(x, gelu=True)
+            assert float((gotg.float() - refg.float()).abs().max()) <= 2 * step * max(1.0, float(refg.abs().max()))
+        x3 = x.view(1, M, K)                                                  # leading dimensions are kept
+        assert lin(x3).shape == (1, M, N)
+    assert not TiledLinear.usable(384, 1536) and not TiledLinear.usable(100, 384)
+    with pytest.raises(ValueError):
+        TiledLinear(torch.zeros((384, 1536), dtype=tdt, device="cuda"))       # K too long: the library GEMM's case
+    with pytest.raises(ValueError):
+        lin(x.float())

@@ -69,6 +69,9 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ts_rope_inplace": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ts_geglu": (c_int32, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_linear_tile_weight": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "ts_linear_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32,
+                                c_void_p]),
     "ts_maxsim_release_scratch": (c_int32, [c_int32]),
     "ts_selftest_device_once": (c_int32, [c_int32, c_int32]),
     "ts_last_error": (c_char_p, []),

@@ -864,6 +864,20 @@ class LeanBertEncoder:
                 "w1": l.intermediate.dense.weight.detach().to(cd), "b1": l.intermediate.dense.bias.detach().to(cd),
                 "w2": l.output.dense.weight.detach().to(cd), "b2": l.output.dense.bias.detach().to(cd),
                 "ln2": (l.output.LayerNorm.weight, l.output.LayerNorm.bias, l.output.LayerNorm.eps)})
+        # projections with a short reduction dimension (Q/K/V, attention output, feed-forward up): weights re-tiled once for
+        # the streamed-weight kernel (ts_linear_act) when they live on a GPU in a 16-bit type
+        self.fused_linear = True
+        self.min_linear_rows = 4096   # below this many tokens the forward is launch-bound and the library GEMM is as good
+        for p in self.layers:
+            p["tqkv"] = p["to"] = p["t1"] = None
+            if compute_dtype in (torch.bfloat16, torch.float16) and p["wqkv"].is_cuda:
+                try:
+                    from .index import TiledLinear
+                    for key, w, b in (("tqkv", "wqkv", "bqkv"), ("to", "wo", "bo"), ("t1", "w1", "b1")):
+                        if TiledLinear.usable(int(p[w].shape[0]), int(p[w].shape[1])):
+                            p[key] = TiledLinear(p[w], p[b])
+                except Exception:
+                    p["tqkv"] = p["to"] = p["t1"] = None    # (no library: the GEMMs stay with torch)
     @torch.no_grad()
     def hidden(self, input_ids, attention_mask, token_type_ids=None, lengths=None):
         """-> (last hidden state float32 [B, L, H], its copy in the compute dtype).  ``lengths`` (int32 [B], optional):
@@ -910,19 +924,26 @@ class LeanBertEncoder:
             abuf = torch.zeros((B, L, H), dtype=cd, device=x.device)   # padded rows stay zero through all layers
         elif attention_mask is not None and not bool(attention_mask.all()):
             mask = attention_mask.to(torch.bool)[:, None, None, :]
+        tl = fused and self.fused_linear and B * L >= self.min_linear_rows      # streamed-weight projections (ts_linear_act)
         for p in self.layers:
-            qkv = F.linear(xb, p["wqkv"], p["bqkv"])
+            qkv = p["tqkv"](xb) if tl and p["tqkv"] is not None else F.linear(xb, p["wqkv"], p["bqkv"])
             if lens is not None:
                 a = attention_varlen(qkv, lens, nh, out=abuf)
             else:
                 qkv = qkv.view(B, L, 3, nh, dh)
                 q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B, heads, L, dh] views
                 a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, L, H)
-            o = F.linear(a, p["wo"], p["bo"])
+            o = p["to"](a) if tl and p["to"] is not None and a.is_contiguous() else F.linear(a, p["wo"], p["bo"])
             x, xb = add_ln(o, x, p["ln1"])
-            f = F.linear(self.act(F.linear(xb, p["w1"], p["b1"])), p["w2"], p["b2"])
+            f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
             x, xb = add_ln(f, x, p["ln2"])
         return x, xb
+
+    def _up(self, p, xb, tl: bool):
+        """The feed-forward up projection with its activation: one kernel (GELU in the epilogue) when it applies."""
+        if tl and p["t1"] is not None:
+            return p["t1"](xb, gelu=True) if self.act is F.gelu else self.act(p["t1"](xb))
+        return self.act(F.linear(xb, p["w1"], p["b1"]))
 
     def __call__(self, input_ids, attention_mask, token_type_ids=None, lengths=None) -> torch.Tensor:
         return self.hidden(input_ids, attention_mask, token_type_ids, lengths)[0]
@@ -950,12 +971,13 @@ class LeanBertEncoder:
         pos = positions if self.kind == "bert" else positions + (self.pad_idx + 1)
         x, xb = embed_layernorm(input_ids, pos, token_type_ids, self.word, self.pos, self.typ, *self.emb_ln, lp_dtype=cd)
         abuf = torch.empty((int(input_ids.shape[0]), int(self.word.shape[-1])), dtype=cd, device=input_ids.device)
+        tl = self.fused_linear and int(input_ids.shape[0]) >= self.min_linear_rows
         for p in self.layers:
-            qkv = F.linear(xb, p["wqkv"], p["bqkv"])
+            qkv = p["tqkv"](xb) if tl and p["tqkv"] is not None else F.linear(xb, p["wqkv"], p["bqkv"])
             a = attention_varlen(qkv, lengths, nh, out=abuf, offs=offsets, max_len=max_len)   # (every row is a valid token)
-            o = F.linear(a, p["wo"], p["bo"])
+            o = p["to"](a) if tl and p["to"] is not None else F.linear(a, p["wo"], p["bo"])
             x, xb = add_layernorm(o, x, *p["ln1"], lp_dtype=cd)
-            f = F.linear(self.act(F.linear(xb, p["w1"], p["b1"])), p["w2"], p["b2"])
+            f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
             x, xb = add_layernorm(f, x, *p["ln2"], lp_dtype=cd)
         return x, xb
 

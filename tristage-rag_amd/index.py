@@ -559,3 +559,39 @@ def embed_layernorm(ids, pos_ids, type_ids, word, pos, typ, gamma, beta, eps: fl
                                       _tensor_dtype(outlp) if outlp is not None else _lib.TS_BF16, dev,
                                       ctypes.c_void_p(_stream_ptr(dev))))
     return out32, outlp
+
+
+class TiledLinear:
+    """A torch.nn.Linear-style weight [N, K] (fp16 / bf16, on the GPU) re-tiled once for ts_linear_act: ``y = act(x W^T + b)``
+    with the weight streamed from L2 and x's rows in LDS — for reduction dimensions up to 768, where the library GEMM
+    re-reads its operands many times.  ``TiledLinear.usable(N, K)`` says whether a shape qualifies."""
+
+    @staticmethod
+    def usable(N: int, K: int) -> bool:
+        return N % 32 == 0 and K % 128 == 0 and K <= 768
+
+    def __init__(self, weight, bias=None):
+        torch = _torch()
+        lib = _lib.load()
+        w = weight.detach().contiguous()
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        if not w.is_cuda or w.dtype not in (torch.float16, torch.bfloat16) or not self.usable(self.N, self.K):
+            raise ValueError("TiledLinear takes a 16-bit CUDA weight [N, K] with N % 32 == 0, K % 128 == 0, K <= 768")
+        self.dtype, self.device = w.dtype, w.device
+        self.bias = bias.detach().to(w.dtype).contiguous() if bias is not None else None
+        self.tiled = torch.empty_like(w)
+        dev = w.device.index
+        _lib.check(lib.ts_linear_tile_weight(ctypes.c_void_p(w.data_ptr()), _tensor_dtype(w), self.N, self.K,
+                                             ctypes.c_void_p(self.tiled.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+
+    def __call__(self, x, gelu: bool = False):
+        torch = _torch()
+        if x.dtype != self.dtype or x.shape[-1] != self.K or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("x must be a contiguous [..., K] tensor of the weight's dtype on its device")
+        out = torch.empty(tuple(x.shape[:-1]) + (self.N,), dtype=x.dtype, device=x.device)
+        dev = x.device.index
+        _lib.check(_lib.load().ts_linear_act(ctypes.c_void_p(self.tiled.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                             ctypes.c_void_p(self.bias.data_ptr()) if self.bias is not None else None,
+                                             _tensor_dtype(x), x.numel() // self.K, self.N, self.K, 1 if gelu else 0,
+                                             ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
+        return out
