@@ -676,7 +676,7 @@ def test_tiled_linear_matches_torch(dt):
     tdt = torch.bfloat16 if dt == "bf16" else torch.float16
     step = 2.0 ** (-8 if dt == "bf16" else -11)
     g = torch.Generator(device="cuda").manual_seed(31)
-    for M, K, N in ((5000, 384, 1152), (4097, 384, 384), (1, 384, 1536), (777, 768, 3072), (100, 768, 768), (300, 128, 32)):
+    for M, K, N in ((5000, 384, 1152), (4097, 384, 384), (1, 384, 1536), (777, 256, 1024), (100, 256, 256), (300, 128, 32)):
         x = (torch.randn((M, K), generator=g, device="cuda") * 0.8).to(tdt)
         w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(tdt)
         b = (torch.randn((N,), generator=g, device="cuda") * 0.1).to(tdt)
@@ -691,7 +691,7 @@ def test_tiled_linear_matches_torch(dt):
             assert float((gotg.float() - refg.float()).abs().max()) <= 2 * step * max(1.0, float(refg.abs().max()))
         x3 = x.view(1, M, K)                                                  # leading dimensions are kept
         assert lin(x3).shape == (1, M, N)
-    assert not TiledLinear.usable(384, 1536) and not TiledLinear.usable(100, 384)
+    assert not TiledLinear.usable(384, 1536) and not TiledLinear.usable(100, 384) and not TiledLinear.usable(3072, 768)
     with pytest.raises(ValueError):
         TiledLinear(torch.zeros((384, 1536), dtype=tdt, device="cuda"))       # K too long: the library GEMM's case
     with pytest.raises(ValueError):

@@ -1,5 +1,6 @@
-// Linear layers of the encoder forwards with a SHORT reduction dimension (K <= 768: the Q/K/V, attention-output and
-// feed-forward "up" projections of MiniLM / BERT-base sized models), optionally with the erf GELU in the epilogue
+// Linear layers of the encoder forwards with a SHORT reduction dimension (K <= 384: the Q/K/V, attention-output and
+// feed-forward "up" projections of MiniLM-class models; at K = 768 the library's stream-K GEMMs are faster and the host
+// keeps them), optionally with the erf GELU in the epilogue
 // (BertIntermediate) — the GEMMs the reference reaches through CrossEncoder.predict / SentenceTransformer.encode
 // (reference src/stage3_reranker.py:127-131, src/stage1_retriever.py:241-249), for gfx950.
 //

@@ -1053,6 +1053,21 @@ class LeanModernBertEncoder:
         if any(p["ln1"] is None for p in self.layers[1:]):
             raise ValueError("unexpected ModernBERT layout")
         self._rope = {}
+        # the projections with a short reduction dimension through the streamed-weight kernel (ts_linear_act), as in
+        # LeanBertEncoder; the MLP's down projection (K = intermediate size) stays a library GEMM
+        self.fused_linear = True
+        self.min_linear_rows = 4096
+        for p in self.layers:
+            p["tqkv"] = p["to"] = p["twi"] = None
+            if compute_dtype in (torch.bfloat16, torch.float16) and p["qkv"][0].is_cuda:
+                try:
+                    from .index import TiledLinear
+                    for key, src in (("tqkv", "qkv"), ("to", "o"), ("twi", "wi")):
+                        w, b = p[src]
+                        if TiledLinear.usable(int(w.shape[0]), int(w.shape[1])):
+                            p[key] = TiledLinear(w, b)
+                except Exception:
+                    p["tqkv"] = p["to"] = p["twi"] = None
 
     def _tables(self, L: int, device):
         """cos / sin [L, head_dim] float32 per layer type, from the module's rotary embedding (positions 0..L-1)."""
@@ -1101,8 +1116,9 @@ class LeanModernBertEncoder:
         else:
             abuf = torch.zeros((B, L, H), dtype=cd, device=dev)
         n = len(self.layers)
+        tl = fused and self.fused_linear and B * L >= self.min_linear_rows
         for i, p in enumerate(self.layers):
-            qkv = F.linear(xb, *p["qkv"])
+            qkv = p["tqkv"](xb) if tl and p["tqkv"] is not None else F.linear(xb, *p["qkv"])
             cos, sin = tables[p["type"]]
             if fused:
                 a = attention_varlen(qkv, lens, nh, out=abuf, window=self.window if p["type"] == "sliding_attention" else 0,
@@ -1112,9 +1128,9 @@ class LeanModernBertEncoder:
                 half = lambda z: torch.cat((-z[..., dh // 2:], z[..., : dh // 2]), dim=-1)
                 q, k = ((z.float() * cos[None, None]) + (half(z.float()) * sin[None, None]) for z in (q, k))
                 a = F.scaled_dot_product_attention(q.to(cd), k.to(cd), v, attn_mask=masks[p["type"]]).transpose(1, 2).reshape(B, L, H)
-            o = F.linear(a, *p["o"])
+            o = p["to"](a) if tl and p["to"] is not None and a.is_contiguous() else F.linear(a, *p["o"])
             x, hb = norm(o, x, p["ln2"], True)
-            u = F.linear(hb, *p["wi"])
+            u = p["twi"](hb) if tl and p["twi"] is not None else F.linear(hb, *p["wi"])
             if fused:
                 g = geglu(u)
             else:
