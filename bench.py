@@ -25,7 +25,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -72,9 +75,105 @@ def parse_args():
                          "(a few microseconds each in-stream).  auto: on for N=1, off for N>1")
     ap.add_argument("--no-encode-leg", action="store_true",
                     help="skip the secondary leg (bi-encoder forward of the 64 query texts + the same search)")
+    ap.add_argument("--no-pipeline-leg", action="store_true",
+                    help="skip the secondary legs that run the full three-stage pipeline (configs[2] shape, search_many of 64 "
+                         "queries, BM25 off and on); N=1 only")
+    ap.add_argument("--no-read-probe", action="store_true",
+                    help="skip the read-only pass over the corpus that gives roofline.measured_read_peak")
+    ap.add_argument("--traffic", choices=["auto", "live", "static", "off"], default="auto",
+                    help="roofline.traffic: live = two rocprofv3 --pmc child runs of this script (FETCH_SIZE, WRITE_SIZE; "
+                         "about half a minute each), static = the number kept in profiles/traffic.json for this shape, "
+                         "auto = live when rocprofv3 is on PATH and N=1, else static")
     ap.add_argument("--encoder", default=None,
                     help="bi-encoder of the secondary leg (default: random:bert with hidden = --dim)")
     return ap.parse_args()
+
+
+def visible_gpus():
+    """Number of HIP devices, counted in a CHILD process: the launcher itself must never initialise the
+    GPU (a process that has may not start the ranks on this pool, and forked HIP state is unusable)."""
+    code = "import torch,sys; sys.stdout.write(str(torch.cuda.device_count()))"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("could not count GPUs: " + r.stderr[-400:])
+    return int(r.stdout.strip().splitlines()[-1])
+
+
+def spawn_ranks(n, cmd, env=None, relay=sys.stdout, log=sys.stderr, timeout=None):
+    """Start `cmd` n times as fresh processes with the torchrun environment (RANK, LOCAL_RANK, WORLD_SIZE,
+    LOCAL_WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT), relay rank 0's stdout to `relay` and every
+    other stream to `log`, and return the exit code: 0 only if EVERY rank exited 0.  When one rank fails the
+    others are terminated by their own pids (they would wait for it in the next collective forever)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n),
+                 "LOCAL_WORLD_SIZE": str(n), "HSA_ENABLE_IPC_MODE_LEGACY": base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                 "TS_BENCH_LAUNCHED_BY": "bench.py"})
+    procs, pumps = [], []
+
+    def pump(src, dst, tag):
+        for line in iter(src.readline, ""):
+            dst.write(tag + line if tag else line)
+            dst.flush()
+        src.close()
+
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        p = subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        for src, dst, tag in ((p.stdout, relay if r == 0 else log, "" if r == 0 else f"[rank {r}] "),
+                              (p.stderr, log, f"[rank {r}] ")):
+            t = threading.Thread(target=pump, args=(src, dst, tag), daemon=True)
+            t.start()
+            pumps.append(t)
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                log.write(f"bench.py launcher: rank {r} exited with {c}; stopping the other ranks\n")
+        if (rc != 0 or (deadline is not None and time.time() > deadline)) and live:
+            if rc == 0:
+                rc = 124
+                log.write("bench.py launcher: timeout; stopping the ranks\n")
+            for r in live:
+                procs[r].terminate()
+            t_end = time.time() + 10
+            for r in list(live):
+                try:
+                    procs[r].wait(max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    for t in pumps:
+        t.join(timeout=5)
+    return rc
+
+
+def launch_self(args):
+    """`python bench.py --gpus N` without a launcher around it: become the launcher.  Nothing in this
+    process has touched HIP (torch is not even imported yet)."""
+    backend = os.environ.get("TS_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and backend == "nccl":
+        have = visible_gpus()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to print a "
+                             f"line that would be mislabelled (TS_BENCH_BACKEND=gloo rehearses the {args.gpus}-rank "
+                             "code path on fewer devices)\n")
+            return 2
+    return spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def gen_rows(torch, n, d, seed, dtype, device):
@@ -171,12 +270,109 @@ def encode_leg(args, torch, index, device, tdt, steps, world):
             "encoder": spec + " (random init, hash tokenizer, bf16 autocast)"}
 
 
+def pipeline_legs(torch):
+    """Secondary, separately reported: the whole three-stage pipeline on the configs[2] shape —
+    3 633 synthetic documents, stage 1 top-1000 -> stage 2 (resident token store, MaxSim) keep 100 -> stage 3
+    (cross-encoder on cached token ids) top-10, bf16, 256 queries through RetrievalPipeline.search_many in calls of
+    64 — with randomly initialised models of the reference's architectures (no weights exist offline: throughput
+    only), once as the benchmark configuration has it (dense stage 1) and once with the reference's default
+    BM25 + RRF fusion.  Exactly bench_pipeline.py's settings for its headline line."""
+    import bench_pipeline
+    out = {}
+    for name, extra in (("pipeline_search_many_qps", []), ("pipeline_search_many_bm25_rrf_qps", ["--bm25"])):
+        r = bench_pipeline.run(bench_pipeline.parse_args(["--queries", "256", "--store", "--many", "64", "--ids"] + extra))
+        out[name] = r["value"]
+        out[name.replace("_qps", "_stage_ms_per_query")] = {k.replace("_time", ""): round(v * 1e3, 4)
+                                                             for k, v in r["mean_stage_seconds"].items()}
+        if "pipeline_config" not in out:
+            out["pipeline_config"] = dict(r["config"], index_build_s=r["index_build_s"], queries=256,
+                                          models="random init, hash tokenizer (throughput only)")
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+def live_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured NOW on this box: two child runs
+    of this script under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need separate passes: MI355X_MICROARCH.md),
+    FETCH_SIZE doubled (gfx950 counts 64 B per 128-B request of a wide streaming read), per launch like `achieved`.
+    The kernel is the one with the largest FETCH_SIZE among the scan kernels (the filter scan reads the whole
+    corpus, the sample scan 0.7 % of it).  Returns (bytes or None, detail)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="ts_pmc_", dir="/tmp")
+    raw = {}
+    kernel = None
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            # the program itself follows `--` (no env/bash hop: the profiler's preload initialises the GPU first)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch),
+                   "--k", str(args.k), "--dtype", args.dtype, "--no-cpu-baseline", "--no-encode-leg", "--no-pipeline-leg",
+                   "--no-read-probe", "--traffic", "off", "--no-profile", "--step-events", "off"]
+            if args.classic:
+                cmd.append("--classic")
+            if args.one_launch:
+                cmd.append("--one-launch")
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                 start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)     # exactly the process group started above
+                p.wait()
+                return None, {"error": f"{counter} pass exceeded 240 s"}
+            if p.returncode != 0:
+                return None, {"error": f"{counter} pass exited with {p.returncode}: {err[-300:]}"}
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, {"error": f"{counter} pass wrote no counter_collection.csv"}
+            per = {}
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            scans = {k: sum(v) / len(v) for k, v in per.items() if "scan" in k or "fused_kernel" in k}
+            if not scans:
+                return None, {"error": f"no scan kernel in the {counter} pass"}
+            if kernel is None:
+                kernel = max(scans, key=scans.get)
+            raw[counter] = (scans.get(kernel, 0.0), len(per.get(kernel, [])))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = round(2 * raw["FETCH_SIZE"][0] * 1024 + raw["WRITE_SIZE"][0] * 1024)
+    return total, {"source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this bench (3 steps each)",
+                   "kernel": kernel[:60], "FETCH_SIZE_KB_raw": round(raw["FETCH_SIZE"][0], 1),
+                   "WRITE_SIZE_KB_raw": round(raw["WRITE_SIZE"][0], 1), "dispatches": raw["FETCH_SIZE"][1],
+                   "correction": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",
+                   "seconds": round(time.time() - t0, 1)}
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_self(args)      # N fresh ranks (RCCL), rank 0's JSON line relayed; non-zero if any rank fails
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # never measure one thing and label it another
+        if int(os.environ.get("RANK", "0")) == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)\n")
+        return 2
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # TS_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks
@@ -198,10 +394,11 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29577")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    if args.gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise RuntimeError(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     device = torch.device("cuda", local_rank)
+    # RCCL needs one device per rank (it refuses duplicates); the gloo rehearsal lets ranks share devices
+    n_devices = world if (backend == "nccl" or world == 1) else min(world, torch.cuda.device_count())
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
 
     from tristage_rag_amd.index import FlatIPIndex
@@ -294,17 +491,38 @@ def main():
     if scan_cnt:
         avg_ms = scan_ms / scan_cnt
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        traffic, traffic_detail = None, None
+        want_live = args.traffic == "live" or (args.traffic == "auto" and world == 1)
+        if want_live and rank == 0:
             try:
-                traffic = json.load(open(tpath)).get(f"{args.rows // world}x{args.dim}x{args.dtype}")
-            except Exception:
-                traffic = None
+                traffic, traffic_detail = live_traffic(args)
+            except Exception as e:   # never take the headline down
+                traffic, traffic_detail = None, {"error": repr(e)}
+        if traffic is None and args.traffic != "off":
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(f"{args.rows // world}x{args.dim}x{args.dtype}")
+                    if traffic is not None:
+                        traffic_detail = dict(traffic_detail or {}, source="static: profiles/traffic.json "
+                                              "(rocprofv3 --pmc passes of an earlier session, same shape)")
+                except Exception:
+                    traffic = None
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
-                "avg_kernel_ms": round(avg_ms, 4), "launches": scan_cnt,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
+                "kernel": kernel, "avg_kernel_ms": round(avg_ms, 4), "launches": scan_cnt,
                 "algorithmic_bytes_per_launch": alg_bytes}
+        if not args.no_read_probe:
+            try:   # the streaming ceiling of THIS box: the scan's access pattern with the arithmetic taken out
+                pr = local.read_probe(reps=5)
+                roof["measured_read_peak"] = round(pr["gbps_avg"], 1)
+                roof["measured_read_peak_best"] = round(pr["gbps_best"], 1)
+                roof["frac_of_measured_read_peak"] = round(achieved / pr["gbps_avg"], 4)
+                roof["read_probe"] = ("ts_index_read_probe: read-only kernel over this index's tiled corpus, same grid / "
+                                      "block order / nt loads as the scan, 5 passes, HIP events")
+            except Exception as e:
+                roof["measured_read_peak"] = None
+                roof["read_probe_error"] = repr(e)
 
     enc_leg = None
     if not args.no_encode_leg:
@@ -312,6 +530,13 @@ def main():
             enc_leg = encode_leg(args, torch, index, device, tdt, max(4, min(args.steps, 20)), world)
         except Exception as e:  # the secondary leg must never take the headline measurement down
             enc_leg = {"error": repr(e)}
+
+    if world == 1 and not args.no_pipeline_leg:
+        try:
+            legs = pipeline_legs(torch)
+            enc_leg = dict(enc_leg or {}, **legs)
+        except Exception as e:
+            enc_leg = dict(enc_leg or {}, pipeline_error=repr(e))
 
     def _rows_label(n):
         return f"{n // 1_000_000}M" if n % 1_000_000 == 0 and n >= 1_000_000 else (
@@ -324,6 +549,10 @@ def main():
             "value": round(args.batch * args.steps / elapsed, 2),
             "unit": "queries/s",
             "n_gpus": world,
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": (("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if dist.is_initialized()
+                        else "none (single process)"),
+            "distinct_devices": n_devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -363,4 +592,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--docs", type=int, default=3633)
     ap.add_argument("--queries", type=int, default=16)
@@ -40,7 +40,12 @@ def main():
     ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args):
+    """Build the pipeline, index the synthetic corpus, time the queries; returns the result record.
+    bench.py calls this for its `pipeline_search_many_qps` legs (same settings as the command line)."""
     import numpy as np
     import torch
     from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
@@ -113,7 +118,7 @@ def main():
     graph_state = {"stage1": None if g1 is None else {"buckets": sorted(g1._graphs), "eager_fallback": g1._broken},
                    "stage2": None if g2 is None else {"buckets": sorted(g2._graphs), "eager_fallback": g2._broken},
                    "stage3": None if g3 is None else {"buckets": sorted(g3._graphs), "eager_fallback": g3._broken}}
-    print(json.dumps({
+    return {
         "metric": "full 3-stage pipeline queries/sec (random-init models, throughput only)",
         "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
@@ -128,7 +133,11 @@ def main():
         "index_build_s": round(t_index, 3), "gemm_tuning_pass_s": (round(t_tune, 1) if t_tune is not None else None),
         "mean_stage_seconds": {k: round(v, 5) for k, v in tm.items()},
         "hip_graph_state": graph_state,
-        "data": "synthetic"}))
+        "data": "synthetic"}
+
+
+def main():
+    print(json.dumps(run(parse_args())))
 
 
 if __name__ == "__main__":

