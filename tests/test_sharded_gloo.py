@@ -122,7 +122,12 @@ def _pipeline_worker(rank, world, port, out_dir):
                 assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (q, stage)
                 np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
             res.append([r["doc_id"] for r in a["results"]])
-        # batched: stage 1 collective, stages 2/3 split by query, one all-gather of the records
+        # what a rank holds: its rows' text only; the records that come back are complete on every rank
+        lo, hi = shard_bounds(57, world, rank)
+        assert len(par.stage1.documents) == 57 and par.stage1.documents.items == docs[lo:hi]
+        for stage in ("stage1_results", "stage2_results", "results"):
+            assert all(r["document"] == docs[r["doc_id"]] for r in a[stage]), stage
+        # batched: stage 1 collective, then every rank scores the candidates / pairs whose documents it owns
         qs = ["neural network retrieval", "gpu memory d7", "zeta", "alpha beta index", "token d3"]
         many, ref = par.search_many(qs), single.search_many(qs)
         assert par.search_many([]) == []
@@ -130,17 +135,19 @@ def _pipeline_worker(rank, world, port, out_dir):
             for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
                 assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
                 np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+                assert [r["document"] for r in a[stage]] == [r["document"] for r in b[stage]]
             res.append([r["doc_id"] for r in a["results"]])
-        again = par.search("gpu memory d7")            # the per-candidate collectives are back in place
+        again = par.search("gpu memory d7")
         assert [r["doc_id"] for r in again["results"]] == res[1]
-        # the array path over the ranks: token store + cached stage-3 token ids on every rank, stages 2/3 split by
-        # query, ONE gather of four small arrays per rank
+        # the array path over the ranks: token store + cached stage-3 token ids ROW-SHARDED with the stage-1 rows
         from doubles import oracle_maxsim_indexed, oracle_maxsim_indexed_batch
 
-        def build_arrays(cls):
+        def build_arrays(cls, **kw):
             p = build(cls)
             p.config.stage2_precompute_document_embeddings = True
             p.config.stage3_cache_document_tokens = True
+            for k, v in kw.items():
+                setattr(p.config, k, v)
             p.stage2 = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=9,
                                                   precompute_document_embeddings=True),
                                      maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed,
@@ -150,25 +157,135 @@ def _pipeline_worker(rank, world, port, out_dir):
         par2._merge_fn = oracle_merge
         par2.add_documents(docs)
         single2.add_documents(docs)
-        assert par2.stage3._pairs_usable and len(par2.stage2.token_store) == len(docs)
+        # rank r holds token matrices / pair-token ids of ITS rows only
+        assert par2.stage3._pairs_usable and len(par2.stage2.token_store) == hi - lo == len(par2.stage3._pairs)
+        assert sorted(par2.stage2._store_slot) == list(range(lo, hi)) and par2.stage3._pairs_base == lo
+        info = par2.get_pipeline_info()["sharding"]
+        assert info["rows"] == [lo, hi] and info["documents_held"] == hi - lo and info["documents_total"] == 57
+        assert info["stage2_token_rows"] == par2.stage2.token_store.rows < single2.stage2.token_store.rows
+        assert info["stage3_id_cache_documents"] == hi - lo
         took = []
-        orig = par2._search_many_arrays_sharded
-        par2._search_many_arrays_sharded = lambda *a, **k: (lambda r: (took.append(r is not None), r)[1])(orig(*a, **k))
+        orig = par2._search_many_arrays
+        par2._search_many_arrays = lambda *a, **k: (lambda r: (took.append(r is not None), r)[1])(orig(*a, **k))
         many2, ref2 = par2.search_many(qs), single2.search_many(qs)
         assert took == [True]
         for a, b in zip(many2, ref2):
             for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
                 assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
                 np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+                assert [r["document"] for r in a[stage]] == [r["document"] for r in b[stage]]
             res.append([r["doc_id"] for r in a["results"]])
+        one = par2.search(qs[1])                                   # search() = the array path of one query
+        assert took == [True, True] and [r["doc_id"] for r in one["results"]] == [r["doc_id"] for r in ref2[1]["results"]]
+        # a query whose candidates ALL live on one rank: dense stage 1 with top_k no larger than the smallest shard and
+        # a query that is (a copy of) a document of rank 0's rows -> check through the merged ids
+        par3 = build_arrays(ShardedRetrievalPipeline, stage1_enable_bm25=False, stage1_top_k=20)
+        single3 = build_arrays(RetrievalPipeline, stage1_enable_bm25=False, stage1_top_k=20)
+        for p3 in (par3, single3):
+            p3.stage1.config.enable_bm25 = False
+        par3._merge_fn = oracle_merge
+        # 40 near-copies of one text at the front (rank 0's rows when world == 2), unrelated text behind them
+        skew = [f"omega omega omega sigma v{i}" for i in range(24)] + [f"lambda kappa d{i}" for i in range(40)]
+        par3.add_documents(skew)
+        single3.add_documents(skew)
+        a3, b3 = par3.search_many(["omega omega omega sigma"])[0], single3.search_many(["omega omega omega sigma"])[0]
+        lo3, hi3 = shard_bounds(len(skew), world, 0)
+        assert all(lo3 <= r["doc_id"] < hi3 for r in a3["stage2_results"]), "the kept candidates were meant to sit on rank 0"
+        for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+            assert [r["doc_id"] for r in a3[stage]] == [r["doc_id"] for r in b3[stage]], stage
+            np.testing.assert_allclose([r[key] for r in a3[stage]], [r[key] for r in b3[stage]], atol=2e-5)
+        res.append([r["doc_id"] for r in a3["results"]])
+        # each rank hands over ONLY its rows (the ingestion call for corpora no host should hold): same results
+        par4 = build_arrays(ShardedRetrievalPipeline, stage1_enable_bm25=False)
+        par4.stage1.config.enable_bm25 = False
+        par4._merge_fn = oracle_merge
+        lo4, hi4 = shard_bounds(len(skew), world, rank)
+        par4.add_documents_shard(skew[lo4:hi4], len(skew))
+        a4 = par4.search_many(["omega omega omega sigma"])[0]
+        assert [r["doc_id"] for r in a4["results"]] == [r["doc_id"] for r in a3["results"]]
+        assert [r["document"] for r in a4["results"]] == [skew[r["doc_id"]] for r in a4["results"]]
         json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_pipeline_equals_single_process_pipeline(tmp_path):
-    """All three stages over 2 ranks (row-sharded stage 1 incl. BM25+RRF, data-parallel stages
-    2 and 3) == the single-process pipeline, and identical on every rank."""
+    """All three stages over 2 ranks — stage-1 rows, stage-2 token store, stage-3 token-id cache and document text all
+    ROW-SHARDED (rank r holds its rows only), BM25+RRF replicated — == the single-process pipeline (ids exact, scores
+    2e-5), identical on every rank; per-record path and array path, a query whose candidates all live on one rank, and
+    the shard-only ingestion call."""
     import json
     mp.spawn(_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert json.load(open(tmp_path / "res0.json")) == json.load(open(tmp_path / "res1.json"))
+
+
+class _CountingAsyncIndex:
+    """OracleIndex with the asynchronous protocol of FlatIPIndex as far as the wrapper sees it: room for 60 passes
+    of <= 32 queries between finish() calls, counted only for searches that actually ran on this rank."""
+
+    def __init__(self, d):
+        from doubles import OracleIndex
+        self._o = OracleIndex(d)
+        self.auto_finish = True
+        self.passes = 0
+        self.finishes = 0
+
+    def __getattr__(self, name):
+        return getattr(self._o, name)
+
+    def search(self, q, k, **kw):
+        self.passes += (q.shape[0] + 31) // 32
+        assert self.passes <= 60, "the wrapper let the local index run out of tickets"
+        return self._o.search(q, k)
+
+    def pending_room(self, n):
+        return 60 - self.passes - (int(n) + 31) // 32
+
+    def finish(self):
+        self.passes = 0
+        self.finishes += 1
+        return []
+
+
+def _empty_shard_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from doubles import oracle_merge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        n, d, k, B = 2, 8, 2, 64                      # 2 rows on 3 ranks: ranks 1 and 2 hold NOTHING ... (ceil division: 1 row each on 0, 1)
+        rng = np.random.default_rng(3)
+        corpus = rng.standard_normal((n, d)).astype(np.float32)
+        idx = ShardedFlatIPIndex(d, n, local_index=_CountingAsyncIndex(d), merge_fn=oracle_merge)
+        idx.add_global(corpus)
+        q = torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32))
+        D0, I0 = idx.search(q, k)
+        idx.local_index.passes = 0                     # (a synchronous search holds no ticket in the real index)
+        calls = []
+        real_finish = idx.finish
+        idx.finish = lambda: (calls.append(len(idx._pending)), real_finish())[1]
+        outs = [idx.search(q, k, async_=True) for _ in range(70)]      # 2 passes each: > 60 passes twice
+        idx.finish()
+        for D, I in outs:
+            assert torch.equal(I, I0) and torch.equal(D, D0)
+        np.save(os.path.join(out_dir, f"calls{rank}.npy"), np.asarray(calls))
+        np.save(os.path.join(out_dir, f"empty{rank}.npy"), np.asarray([idx.hi - idx.lo]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_finish_cadence_is_the_same_on_ranks_with_empty_shards(tmp_path):
+    """the wrapper's finish() is collective (an all_reduce + re-exchange) but was triggered by the LOCAL
+    index running out of tickets — which never happens on a rank whose shard is empty (fewer rows than ranks), so
+    after ~30 asynchronous 64-query batches the non-empty ranks sat in the all_reduce and the empty ones in the
+    next all_gather.  The cadence now follows the wrapper's own count: identical finish points on every rank."""
+    world = 3
+    mp.spawn(_empty_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    calls = [np.load(tmp_path / f"calls{r}.npy").tolist() for r in range(world)]
+    sizes = [int(np.load(tmp_path / f"empty{r}.npy")[0]) for r in range(world)]
+    assert 0 in sizes and max(sizes) > 0                       # at least one empty and one non-empty shard
+    assert calls[0] == calls[1] == calls[2] and len(calls[0]) >= 3   # two forced finishes + the final one

@@ -476,8 +476,7 @@ class RetrievalPipeline:
         if self.stage2 is not None and self.stage2.config.precompute_document_embeddings and self.stage1.documents:
             # the resident stage-2 token store comes back from its file, or is re-encoded
             if not self.stage2.load_token_store(self._token_store_path(index_path), len(self.stage1.documents)):
-                from .stage2_rescorer import TokenStore
-                self.stage2.token_store, self.stage2._store_slot = TokenStore(), {}
+                self.stage2.reset_token_store()
                 self.stage2.index_documents(list(self.stage1.documents), 0)
         if self.stage3 is not None and self.config.stage3_cache_document_tokens and self.stage1.documents:
             self.stage3._pairs = None     # token ids are cheap to recompute: no file of their own

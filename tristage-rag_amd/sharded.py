@@ -70,6 +70,7 @@ class ShardedFlatIPIndex:
             self.merge_packed_fn = merge_topk_packed   # reads the all-gather buffer in place
         self.merge_fn = merge_fn
         self._pending = []
+        self._pending_passes = 0      # scan passes of the pending batches, counted HERE so every rank counts alike
         self.always_exchange = False  # tests: run the collective + merge even for one rank
 
     # -- FAISS duck type ----------------------------------------------------
@@ -105,9 +106,14 @@ class ShardedFlatIPIndex:
             # writes into lives on the index's GPU, so the queries go there first
             q = q.to(dev)
         B = q.shape[0]
-        if async_ and (len(self._pending) >= 48 or
-                       (hasattr(self.local_index, "pending_room") and self.local_index.pending_room(B) < 0)):
-            self.finish()   # collective: every rank sees the same sequence of batch sizes
+        # finish() is COLLECTIVE, so its cadence must follow state that is identical on every rank: the batches seen
+        # by this wrapper.  (Round 2 asked the local index for room — but a rank with an empty shard, e.g. 17 rows
+        # on 8 ranks, never searches locally, never ran out of room, and met the others' all_reduce with its next
+        # all_gather: a hang after ~30 batches.)  60 passes of <= 32 queries is the local index's own limit, which
+        # it can only reach later than this count does.
+        passes = (B + 31) // 32
+        if async_ and self._pending_passes and (len(self._pending) >= 48 or self._pending_passes + passes > 60):
+            self.finish()
         # the local result is produced directly inside the buffer that is exchanged:
         # [float32 scores | pad to 8 | int64 ids], no packing kernels
         from .index import packed_layout
@@ -125,6 +131,8 @@ class ShardedFlatIPIndex:
         else:  # an empty shard contributes only padding
             D.fill_(-3.4028234663852886e38)
             I.fill_(-1)
+        if async_:
+            self._pending_passes += passes
         if self.world_size == 1 and not self.always_exchange:
             return D, I
         out = self._exchange_and_merge(packed, B, k)
@@ -180,6 +188,7 @@ class ShardedFlatIPIndex:
         redone_local = set(self.local_index.finish()) if hasattr(self.local_index, "finish") else set()
         if (self.world_size == 1 and not self.always_exchange) or not self._pending:
             self._pending.clear()
+            self._pending_passes = 0
             return
         # the i-th pending entry of every rank is the same batch; local tickets are
         # consecutive, so "repeated" maps to positions from the end
@@ -202,6 +211,7 @@ class ShardedFlatIPIndex:
             out[1].copy_(In)
         torch.cuda.current_stream().synchronize() if flags.is_cuda else None
         self._pending.clear()
+        self._pending_passes = 0
 
     def _last_ticket(self) -> int:
         li = self.local_index

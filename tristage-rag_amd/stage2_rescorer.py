@@ -131,6 +131,7 @@ class ColBERTScorer:
         self._doc_cache: Dict[str, torch.Tensor] = {}
         self.token_store = TokenStore()        # filled by index_documents()
         self._store_slot: Dict[int, int] = {}  # pipeline doc_id -> slot in the store
+        self._slot_version = 0                 # bumped whenever _store_slot is replaced or extended (see _slot_table)
         self._graphed = None
         self._load_model()
 
@@ -312,6 +313,7 @@ class ColBERTScorer:
             self.token_store.append_packed(rows, mask.sum(dim=1).tolist())
             for j, i in enumerate(idx):
                 self._store_slot[first_doc_id + i] = base + j
+        self._slot_version += 1
 
     # -- persistence of the token store (additive; the reference has nothing to persist for stage 2)
     def save_token_store(self, path: str) -> bool:
@@ -351,6 +353,7 @@ class ColBERTScorer:
         st.starts, st.lens = [int(x) for x in starts.tolist()], [int(x) for x in lens.tolist()]
         self.token_store = st
         self._store_slot = {int(d): j for j, d in enumerate(ids.tolist())}
+        self._slot_version += 1
         return True
 
     def _score_from_store(self, query_embeddings: torch.Tensor, candidates: List[Dict[str, Any]]):
@@ -438,20 +441,75 @@ class ColBERTScorer:
                   self.config.scoring_method).detach().cpu().tolist()
         return [[float(x) for x in flat[a:b]] for a, b in zip(c_off[:-1], c_off[1:])]
 
-    def _slot_table(self, device) -> Optional[torch.Tensor]:
-        """int64 [max doc id + 1]: pipeline doc id -> slot of the token store (-1 = not in the store)."""
-        n = len(self._store_slot)
-        cached = getattr(self, "_slot_tab", None)
-        if cached is not None and cached[0] == n and cached[1].device == torch.device(device):
-            return cached[1]
-        if not n:
+    def reset_token_store(self) -> None:
+        """Drop the resident token store (and every table derived from it)."""
+        self.token_store, self._store_slot = TokenStore(), {}
+        self._slot_version += 1
+
+    def _slot_table(self, device):
+        """(base, int64 [max id - base + 1]): pipeline doc id -> slot of the token store (-1 = not in the store), for
+        the id range this store covers — a row shard's store starts at its first row, not at 0.  None for an empty
+        store.  The cache is keyed on a version counter that every writer of ``_store_slot`` bumps (round 2 keyed it on
+        the document COUNT: a reloaded store of the same size kept the old table and scored other documents' tokens)."""
+        if not self._store_slot:
             return None
-        tab = torch.full((max(self._store_slot) + 1,), -1, dtype=torch.int64)
-        tab[torch.tensor(list(self._store_slot.keys()), dtype=torch.int64)] = torch.tensor(
-            list(self._store_slot.values()), dtype=torch.int64)
-        tab = tab.to(device)
-        self._slot_tab = (n, tab)
-        return tab
+        cached = getattr(self, "_slot_tab", None)
+        key = (self._slot_version, id(self._store_slot), str(torch.device(device)))
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        keys = torch.tensor(list(self._store_slot.keys()), dtype=torch.int64)
+        base = int(keys.min())
+        tab = torch.full((int(keys.max()) - base + 1,), -1, dtype=torch.int64)
+        tab[keys - base] = torch.tensor(list(self._store_slot.values()), dtype=torch.int64)
+        out = (base, tab.to(device))
+        self._slot_tab = (key, out)
+        return out
+
+    def score_arrays_partial(self, queries: List[str], cand_ids: torch.Tensor) -> torch.Tensor:
+        """MaxSim scores float32 [B, C] of the candidates ``cand_ids`` int64 [B, C] that live in THIS process's token
+        store; -inf everywhere else (ids outside the store's range, padding ids < 0).  One padded query forward, one
+        ts_maxsim_indexed_batch launch over the owned candidates (ragged per query), no collective.  With a
+        row-sharded store (parallel_pipeline.ShardedRetrievalPipeline) every candidate is owned by exactly one rank,
+        so an element-wise MAX over the ranks yields the complete score matrix."""
+        store = self.token_store
+        dev = store.data.device if store.data is not None else cand_ids.device
+        cand_ids = cand_ids.to(dev)
+        B, C = cand_ids.shape
+        out = torch.full((B, C), float("-inf"), dtype=torch.float32, device=dev)
+        got = self._slot_table(dev) if len(store) else None
+        if got is None or B == 0 or C == 0:
+            return out
+        base, tab = got
+        rel = cand_ids - base
+        inside = (rel >= 0) & (rel < tab.numel())
+        slots = torch.where(inside, tab[rel.clamp(0, tab.numel() - 1)], torch.full_like(rel, -1))
+        owned = slots >= 0
+        counts = owned.sum(dim=1).tolist()            # the one host sync of the step: ragged candidate offsets
+        if sum(counts) == 0:
+            return out
+        q_embs = self.encode_queries_batch(list(queries))
+        starts_all, lens_all = store.device_tables()
+        dt = store.data.dtype
+        q_off, c_off = [0], [0]
+        for e, c in zip(q_embs, counts):
+            q_off.append(q_off[-1] + int(e.shape[0]))
+            c_off.append(c_off[-1] + int(c))
+        q_packed = torch.cat([e.to(dt) for e in q_embs], 0).contiguous()
+        sel = slots[owned]                            # row-major: grouped by query, stage-1 order inside a query
+        fn = self._maxsim_indexed_batch_fn
+        if fn is None:
+            from .index import maxsim_indexed_batch  # HIP kernel; raises without the library or a GPU
+            fn = maxsim_indexed_batch
+        flat = fn(q_packed, q_off, store.data, starts_all[sel], lens_all[sel], c_off, self.config.scoring_method)
+        out[owned] = flat.to(dev).to(torch.float32)
+        return out
+
+    def keep_top_arrays(self, sc: torch.Tensor):
+        """Stable descending sort of the score matrix [B, C] (= the reference's stable ``sort``, :293-297) ->
+        (pos int64 [B, keep], scores float32 [B, keep]), keep = top_k_candidates."""
+        srt, pos = torch.sort(sc, dim=1, descending=True, stable=True)
+        keep = min(self.config.top_k_candidates, sc.shape[1])
+        return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
 
     def rescore_arrays(self, queries: List[str], cand_ids: torch.Tensor):
         """rescore_many on arrays: ``cand_ids`` int64 [B, C] (CUDA; every row the stage-1 candidates of that
@@ -460,34 +518,12 @@ class ColBERTScorer:
         sort of the reference (:293-297) — and their scores.  Everything stays on the GPU: one padded query
         forward, one MaxSim launch over the resident token store, one sort.  None if a candidate is not in
         the store."""
-        store = self.token_store
-        if not len(store) or cand_ids.dim() != 2:
+        if not len(self.token_store) or cand_ids.dim() != 2:
             return None
-        cand_ids = cand_ids.to(store.data.device)
-        tab = self._slot_table(cand_ids.device)
-        B, C = cand_ids.shape
-        if tab is None or int(cand_ids.max()) >= tab.numel() or int(cand_ids.min()) < 0:
+        sc = self.score_arrays_partial(queries, cand_ids)
+        if bool(torch.isinf(sc).any()):               # (a MaxSim score is a mean of cosines: never infinite)
             return None
-        slots = tab[cand_ids.reshape(-1)]
-        if bool((slots < 0).any()):
-            return None
-        q_embs = self.encode_queries_batch(list(queries))
-        starts_all, lens_all = store.device_tables()
-        dt = store.data.dtype
-        q_off = [0]
-        for e in q_embs:
-            q_off.append(q_off[-1] + int(e.shape[0]))
-        c_off = [j * C for j in range(B + 1)]
-        q_packed = torch.cat([e.to(dt) for e in q_embs], 0).contiguous()
-        fn = self._maxsim_indexed_batch_fn
-        if fn is None:
-            from .index import maxsim_indexed_batch  # HIP kernel; raises without the library or a GPU
-            fn = maxsim_indexed_batch
-        flat = fn(q_packed, q_off, store.data, starts_all[slots], lens_all[slots], c_off, self.config.scoring_method)
-        sc = flat.to(cand_ids.device).view(B, C)
-        srt, pos = torch.sort(sc, dim=1, descending=True, stable=True)
-        keep = min(self.config.top_k_candidates, C)
-        return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
+        return self.keep_top_arrays(sc)
 
     def _keep_top(self, candidates: List[Dict[str, Any]], scores: List[float]) -> List[Dict[str, Any]]:
         scored = []

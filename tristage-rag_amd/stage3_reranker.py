@@ -189,8 +189,10 @@ class CrossEncoderReranker:
     # -- token-id level path (additive): documents tokenised once, pairs assembled on the GPU ------------
     def index_documents(self, documents: List[str], first_doc_id: int) -> bool:
         """Tokenise `documents` once and keep their ids for rerank_arrays(); document j gets pipeline id
-        first_doc_id + j.  False (and the id cache is dropped) when the tokenizer cannot be restated on the
-        device (encoders.PairAssembler probes it) or the ids are not consecutive from 0."""
+        first_doc_id + j.  The FIRST call fixes the id of slot 0 (0 for a whole corpus, the first row of a row shard:
+        parallel_pipeline.ShardedRetrievalPipeline); later calls must continue where the previous one ended.  False
+        (and the id cache is unusable) when the tokenizer cannot be restated on the device (encoders.PairAssembler
+        probes it) or the ids are not consecutive."""
         from .encoders import CrossEncoderModel, PairAssembler
         if not isinstance(self.model, CrossEncoderModel):
             self._pairs = None
@@ -199,65 +201,94 @@ class CrossEncoderReranker:
         if pa is None:
             pa = PairAssembler(self.model.tokenizer, self.config.max_length)
             self._pairs = pa
-        if not pa.ok or first_doc_id != len(pa):
+            self._pairs_base = int(first_doc_id)
+        if not pa.ok or first_doc_id != self._pairs_base + len(pa):
             self._pairs_usable = False
             return False
         pa.add_documents(documents)
         self._pairs_usable = True
         return True
 
-    def rerank_arrays(self, queries: List[str], doc_ids: torch.Tensor):
-        """rerank_many on arrays: doc_ids int64 [B, C] (CUDA; row q = the stage-2 list of query q, in stage-2
-        order) -> (pos int64 [B, keep], scores float64 [B, keep]): positions in stage-2 order of the
-        ``top_k_final`` best by stage-3 score (min-max normalised per query like reference :212-228, stable
-        descending sort :256-260).  The (query, document) inputs are assembled from cached token ids on the GPU
-        with the tokenizer's own truncation, run through the cross-encoder in length-sorted batches of
-        ``many_batch_size`` pairs.  None when the id cache does not cover the documents."""
+    def raw_arrays_partial(self, queries: List[str], doc_ids: torch.Tensor) -> torch.Tensor:
+        """Activated cross-encoder scores float32 [B, C] of the pairs (queries[q], document doc_ids[q, j]) whose
+        document lives in THIS process's token-id cache; -inf everywhere else.  The (query, document) inputs are
+        assembled from cached token ids on the GPU with the tokenizer's own truncation and run through the
+        cross-encoder in length-sorted batches of ``many_batch_size`` pairs (packed when the written-out forward
+        takes them); no collective.  With a row-sharded cache every pair is owned by exactly one rank."""
         pa = getattr(self, "_pairs", None)
-        if pa is None or not getattr(self, "_pairs_usable", False) or doc_ids.dim() != 2:
-            return None
-        B, C = doc_ids.shape
-        if B == 0 or C == 0 or int(doc_ids.max()) >= len(pa) or int(doc_ids.min()) < 0:
-            return None
-        dev = torch.device(self.model.device)
+        dev = torch.device(self.model.device) if hasattr(self.model, "device") else doc_ids.device
         doc_ids = doc_ids.to(dev)
+        B, C = doc_ids.shape
+        raw_full = torch.full((B * C,), float("-inf"), dtype=torch.float32, device=dev)
+        if pa is None or not getattr(self, "_pairs_usable", False) or not len(pa) or B == 0 or C == 0:
+            return raw_full.view(B, C)
+        base = int(getattr(self, "_pairs_base", 0))
+        flat_ids = doc_ids.reshape(-1)
+        owned = (flat_ids >= base) & (flat_ids < base + len(pa))
+        whole = B * C
+        idx = torch.nonzero(owned).flatten()          # positions (row-major) of the owned pairs
+        P = int(idx.numel())                          # host sync (the plan below has one anyway)
+        if P == 0:
+            return raw_full.view(B, C)
         q_ids = [pa.ids_of(q) for q in queries]
-        pair_q = torch.arange(B, device=dev).repeat_interleave(C)
-        plan = pa.plan(q_ids, pair_q, doc_ids.reshape(-1), dev)
+        pair_q = torch.div(idx, C, rounding_mode="floor")
+        plan = pa.plan(q_ids, pair_q, flat_ids[idx] - base, dev)
         order = torch.argsort(plan["total"], descending=True, stable=True)
-        raw = torch.empty((B * C,), dtype=torch.float32, device=dev)
+        raw = torch.empty((P,), dtype=torch.float32, device=dev)
         wm = max(int(getattr(self.config, "many_width_multiple", 1) or 1), 1)
         bs = max(self.config.batch_size, self.config.many_batch_size)
         # packed batches (no padded position in the GEMMs, LayerNorms or GELU) whenever the written-out forward takes them
-        graph_one = B * C <= bs and getattr(self.model, "use_hip_graph", False)    # one query's pairs: the replayed graph wins
+        graph_one = P <= bs and P == whole and getattr(self.model, "use_hip_graph", False)    # one query's pairs: the replayed graph wins
         packed = (wm == 1 and not graph_one and getattr(self.config, "many_packed", True) and hasattr(self.model, "packed_ok")
-                  and self.model.packed_ok(int(self.config.max_length), min(max(bs, int(getattr(self.config, "many_packed_batch_size", bs))), B * C)))
+                  and self.model.packed_ok(int(self.config.max_length), min(max(bs, int(getattr(self.config, "many_packed_batch_size", bs))), P)))
         if packed:
             bs = max(bs, int(getattr(self.config, "many_packed_batch_size", bs)))
         tot = plan["total"][order]
         csum = torch.cumsum(tot, 0)
-        ends = torch.arange(bs, B * C + bs, bs, device=dev).clamp(max=B * C) - 1
+        ends = torch.arange(bs, P + bs, bs, device=dev).clamp(max=P) - 1
         host = torch.stack([tot[::bs], csum[ends]]).tolist()      # one host sync: every batch's padded width and token count
         widths = host[0]
         tokens = [int(e - s) for e, s in zip(host[1], [0] + host[1][:-1])]
         if wm > 1:                                            # (padding is masked: same scores up to batch-padding noise)
             widths = [min(-(-int(w) // wm) * wm, max(int(self.config.max_length), int(w))) for w in widths]
-        for j, s in enumerate(range(0, B * C, bs)):
+        for j, s in enumerate(range(0, P, bs)):
             sel = order[s: s + bs]
             if packed:
                 enc = pa.batch_packed(plan, sel, tokens[j], int(widths[j]))
                 raw[sel] = self.model.activate(self.model.logits_from_ids(enc)).reshape(-1)
                 continue
             enc = pa.batch(plan, sel, width=int(widths[j]))
-            lg = self.model.logits_graphed(enc) if B * C <= bs else None   # one query's pairs: graph replay if enabled
+            lg = self.model.logits_graphed(enc) if graph_one or (P <= bs and P == whole) else None   # one query's pairs: graph replay if enabled
             raw[sel] = self.model.activate(lg if lg is not None else self.model.logits_from_ids(enc)).reshape(-1)
-        a = raw.view(B, C).to(torch.float64)
+        raw_full[idx] = raw
+        return raw_full.view(B, C)
+
+    def finish_arrays(self, raw: torch.Tensor):
+        """raw activated scores [B, C] -> (pos int64 [B, keep], scores float64 [B, keep]): min-max per query in
+        float64 like reference :212-228 (all-equal -> zeros), stable descending sort (:256-260), top_k_final."""
+        a = raw.to(torch.float64)
         if self.config.normalize_scores:
             mn, mx = a.min(dim=1, keepdim=True).values, a.max(dim=1, keepdim=True).values
             a = torch.where(mx > mn, (a - mn) / (mx - mn), torch.zeros_like(a))
         srt, pos = torch.sort(a, dim=1, descending=True, stable=True)
-        keep = min(self.config.top_k_final, C)
+        keep = min(self.config.top_k_final, raw.shape[1])
         return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
+
+    def rerank_arrays(self, queries: List[str], doc_ids: torch.Tensor):
+        """rerank_many on arrays: doc_ids int64 [B, C] (CUDA; row q = the stage-2 list of query q, in stage-2
+        order) -> (pos int64 [B, keep], scores float64 [B, keep]): positions in stage-2 order of the
+        ``top_k_final`` best by stage-3 score (min-max normalised per query like reference :212-228, stable
+        descending sort :256-260).  None when the id cache does not cover the documents."""
+        pa = getattr(self, "_pairs", None)
+        if pa is None or not getattr(self, "_pairs_usable", False) or doc_ids.dim() != 2:
+            return None
+        B, C = doc_ids.shape
+        if B == 0 or C == 0:
+            return None
+        raw = self.raw_arrays_partial(queries, doc_ids)
+        if bool(torch.isinf(raw).any()):              # a document outside the id cache
+            return None
+        return self.finish_arrays(raw)
 
     def batch_rerank(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]):
         if not queries or not candidates_list:
@@ -290,6 +321,7 @@ class AdaptiveCrossEncoderReranker(CrossEncoderReranker):
         self.max_text_length = config.max_length // 2
 
     def _adaptive_batch_size(self, texts: List[str]) -> int:
+        texts = [t for t in texts if t is not None]   # (a row-sharded pipeline: text lives with its owner rank only)
         if not texts:
             return self.config.batch_size
         avg = sum(len(t.split()) for t in texts) / len(texts)
