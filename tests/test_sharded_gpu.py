@@ -221,3 +221,75 @@ def test_merge_of_more_lists_than_fit_one_workgroup(R, k, B):
     D0, I0 = oracle.merge_topk(scores, ids, k)
     D, I = merge_topk(torch.from_numpy(scores).cuda(), torch.from_numpy(ids).cuda())
     assert np.array_equal(I.cpu().numpy(), I0) and np.array_equal(D.cpu().numpy(), D0)
+
+
+def _sharded_pipeline_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from pipeline_pairs import synth_docs
+    from tristage_rag_amd.parallel_pipeline import ShardedRetrievalPipeline
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    from tristage_rag_amd.sharded import shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        docs = synth_docs(601, seed=5)
+        queries = ["neural networks attention", "language retrieval system", "gpu memory index", docs[11], "vector search rank",
+                   docs[590]]
+
+        def cfg(name, bm25):
+            return PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                                  device="cuda", cache_dir=os.path.join(out_dir, "m"), index_dir=os.path.join(out_dir, "i"),
+                                  log_file=os.path.join(out_dir, f"{name}{rank}.log"), log_level="WARNING", stage1_top_k=200,
+                                  stage2_top_k=40, stage3_top_k=10, stage1_enable_bm25=bm25, stage1_use_fp16=False,
+                                  stage2_use_fp16=False, stage3_use_fp16=False, save_intermediate_results=True,
+                                  stage2_precompute_document_embeddings=True, stage3_cache_document_tokens=True)
+        res = {}
+        for bm25 in (False, True):
+            par = ShardedRetrievalPipeline(config=cfg("par", bm25))
+            par.add_documents(docs)
+            lo, hi = shard_bounds(len(docs), world, rank)
+            info = par.get_pipeline_info()["sharding"]
+            assert info["rows"] == [lo, hi] and len(par.stage2.token_store) == hi - lo == len(par.stage3._pairs)
+            assert par._arrays_agreed()
+            many = par.search_many(queries)
+            one = par.search(queries[3])
+            single = RetrievalPipeline(config=cfg("one", bm25))
+            single.add_documents(docs)
+            assert info["stage2_token_rows"] < single.stage2.token_store.rows
+            ref = single.search_many(queries)
+            for a, b in zip(many + [one], ref + [ref[3]]):
+                for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                    ia, ib = [x["doc_id"] for x in a[stage]], [x["doc_id"] for x in b[stage]]
+                    sa, sb = np.array([x[key] for x in a[stage]]), np.array([x[key] for x in b[stage]])
+                    assert len(ia) == len(ib), (stage, len(ia), len(ib))
+                    np.testing.assert_allclose(sa, sb, atol=2e-5)     # fp32 models: the batches differ in shape only
+                    for x, y, u, v in zip(ia, ib, sa, sb):
+                        assert x == y or abs(u - v) < 2e-5, (stage, x, y, u, v)
+                    assert all(x["document"] == docs[x["doc_id"]] for x in a[stage])
+            res[str(bm25)] = [[x["doc_id"] for x in a["results"]] for a in many]
+        json.dump(res, open(os.path.join(out_dir, f"ids{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_three_stage_pipeline_on_the_real_kernels(tmp_path):
+    """Two PROCESSES on the one GPU of the test box (gloo group, collectives staged through the host), each holding
+    its half of the rows in the HIP index, its half of the stage-2 token store and its half of the stage-3 token-id
+    cache: the array path of search_many / search — owner-scored MaxSim (ts_maxsim_indexed_batch on ragged owned
+    candidates) and cross-encoder pairs, one all-reduce(MAX) per stage — equals the single-process pipeline (ids
+    exact up to 2e-5 near-ties, scores 2e-5), dense and with BM25 + RRF, and is identical on both ranks."""
+    import json
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sharded_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert json.load(open(tmp_path / "ids0.json")) == json.load(open(tmp_path / "ids1.json"))
