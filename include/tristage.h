@@ -136,6 +136,12 @@ int ts_index_scores(ts_index* h, const void* queries, int32_t nq, int32_t q_dtyp
  * returned in failed_tickets[0..*n_failed) and must be repeated by the caller
  * with TS_FLAG_NO_FILTER (synchronously).  At most 64 calls may be unfinished.  */
 int64_t ts_index_last_ticket(const ts_index* h);
+/* 1 if a search for top-k on this index takes the threshold-filter path (exact only once verified: a synchronous
+ * call verifies before it returns, an asynchronous one in ts_index_finish), 0 if it takes the dense path, whose result
+ * is exact by construction — an asynchronous search is then final when the stream reaches it, so a caller may consume
+ * it in stream order without waiting (the per-query path of RetrievalPipeline.search on small corpora: no host sync
+ * between faiss_index.search, reference src/stage1_retriever.py:380, and stage 2).  Negative: error.          */
+int ts_index_filter_path(const ts_index* h, int32_t k);
 int ts_index_finish(ts_index* h, void* stream, int64_t* failed_tickets, int32_t max_failed,
                     int32_t* n_failed);
 

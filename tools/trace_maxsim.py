@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave phase timeline of ONE single-query MaxSim launch (needs a -DTS_TUNING -DM16_TRACE build
-in TRISTAGE_LIB).  Phases: 0 entry, 1 query image staged, 2 prefix sums + barrier, 3 slice found and
-ring issued, 4 query norms, 5 first tile done, 6 slice done, 7 records flushed."""
+in TRISTAGE_LIB).  Phases: 0 entry, 1 prefix sums + barrier, 2 slice found and ring issued, 3 query image in LDS
+(+ barrier), 4 query norms, 5 first tile done, 6 slice done, 7 records flushed."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,12 +22,13 @@ for rep in range(4):
     out = maxsim_indexed(q, store, starts_all[pk].contiguous(), lens_all[pk].to(torch.int32).contiguous())
     torch.cuda.synchronize()
 assert lib.ts_debug_m16_trace(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)[:1024]
+t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)[:2048]
+t = t[t[:, 0] > 0]
 act = t[:, 7] > 0
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
-names = ["entry", "q image staged", "prefix+barrier", "slice+ring issued", "q norms", "first tile", "slice done", "flushed"]
-print(f"docs={docs}: {int(act.sum())} active waves of 1024")
+names = ["entry", "prefix+barrier", "slice+ring issued", "q image in LDS", "q norms", "first tile", "slice done", "flushed"]
+print(f"docs={docs}: {int(act.sum())} active waves of {t.shape[0]} launched")
 for i, n in enumerate(names):
     col = us[act, i] if i >= 3 else us[:, i]
     print(f"  {i} {n:20s} min {col.min():7.2f}  median {np.median(col):7.2f}  p95 {np.percentile(col, 95):7.2f}  max {col.max():7.2f} us")

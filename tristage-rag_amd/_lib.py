@@ -50,6 +50,7 @@ SIGNATURES = {
     "ts_index_reconstruct": (c_int32, [c_void_p, c_int64, c_int64, c_void_p, c_uint32, c_void_p]),
     "ts_index_last_search_info": (c_int32, [c_void_p, POINTER(c_int64)]),
     "ts_index_last_ticket": (c_int64, [c_void_p]),
+    "ts_index_filter_path": (c_int32, [c_void_p, c_int32]),
     "ts_index_finish": (c_int32, [c_void_p, c_void_p, POINTER(c_int64), c_int32, POINTER(c_int32)]),
     "ts_index_set_profiling": (c_int32, [c_void_p, c_int32]),
     "ts_index_get_timings": (c_int32, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int32]),

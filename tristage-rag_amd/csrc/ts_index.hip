@@ -989,6 +989,15 @@ extern "C" int ts_index_scores(ts_index* h, const void* queries, int32_t nq, int
   return TS_OK;
 }
 
+// 1 = a search with this k goes through the threshold filter (its result has to be VERIFIED: a synchronous call does
+// it, an asynchronous one leaves it to ts_index_finish), 0 = it takes the dense path, which is exact by construction —
+// an asynchronous search is then final as soon as the stream reaches it.  Mirrors search_pass_on.
+extern "C" int ts_index_filter_path(const ts_index* h, int32_t k) {
+  if (!h || k <= 0) { ts_set_error("bad arguments to filter_path"); return TS_ERR_INVALID; }
+  const int64_t N = h->ntotal;
+  return (k <= kMaxFilterK && N >= kMinFilterRows && N >= 32 * (int64_t)k) ? 1 : 0;
+}
+
 extern "C" int64_t ts_index_last_ticket(const ts_index* h) {
   if (!h) return -1;
   std::lock_guard<std::mutex> lk(const_cast<ts_index*>(h)->mu);

@@ -370,16 +370,9 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     len = m16_len_s(p, doc);
     start = m16_start_s(p, doc);
   }
-  const unsigned char* cur = p.docs;
-  u32x4 ring[M16_RING];
-  if (has_work) {
-    const int rows = min(32, len - tile * 32);
-    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
-#pragma unroll
-    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
-  }
-  M16_STAMP(2);
-
+  // (Round 3: the image is staged BEFORE the ring's first loads go out.  Round 2 requested it after them: loads
+  // return in order, so it sat behind 1024 waves x 16 KiB of first ring loads and was complete only at 8.3 us — ring
+  // issued at 4.4 us, first tile done at 16.4 us, every wave idling on a full ring for ~2 us; tools/trace_maxsim.py.)
   // ---- Q image: unit (g*NQT + t)*64 + l = the 16 bytes at byte 32g + 16(l>>5) of query row q0 + 32t + (l&31)
   // (8 independent L2 reads in flight per thread: one at a time costs ~1 us each)
   {
@@ -410,6 +403,16 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   // are needed next anyway.)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
   __syncthreads();
+  const unsigned char* cur = p.docs;
+  u32x4 ring[M16_RING];
+  if (has_work) {
+    const int rows = min(32, len - tile * 32);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
+#pragma unroll
+    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
+  }
+  M16_STAMP(2);
+
   if (!has_work) return;  // (no block-level barrier below)
 
   M16_STAMP(3);

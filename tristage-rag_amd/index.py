@@ -232,6 +232,15 @@ class FlatIPIndex:
             raise ValueError("No documents indexed. Call add_documents() first.")
         _lib.check(code)
 
+    def search_in_stream_order(self, q, k: int):
+        """search() for a caller that consumes (D, I) on the current stream only: when the dense path will be taken
+        (small corpora, k > 2048 — exact by construction) the search is just ENQUEUED and the host does not wait; on the
+        filter path it is the ordinary synchronous, verified search.  CUDA tensor queries only."""
+        path = int(self._lib.ts_index_filter_path(self._h, int(k)))
+        if path != 0 or not (_is_tensor(q) and q.is_cuda) or not self.auto_finish:
+            return self.search(q, k)
+        return self.search(q, k, async_=True)     # (its ticket is retired by the next finish(); nothing to verify)
+
     def pending_room(self, n_queries: int) -> int:
         """>= 0 while another asynchronous search of `n_queries` queries fits before a finish()."""
         return 60 - self._pending_passes - (int(n_queries) + 31) // 32

@@ -184,6 +184,10 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
             self.stage2.index_documents(mine, lo)          # token matrices of MY rows only
         if self.stage3 is not None and self.config.stage3_cache_document_tokens and mine:
             self.stage3.index_documents(mine, lo)          # cross-encoder token ids of MY rows only
+        if self.world_size > 1:      # a rank owns ~1/R of any candidate list: score the owned ones only (ragged launches)
+            for st in (self.stage2, self.stage3):
+                if st is not None:
+                    st.owner_compact = True
         self._install_owner_scoring()
         self._indexed = True
 

@@ -328,6 +328,11 @@ class RetrievalPipeline:
             return None
         n = len(queries)
         total_start = t = self._tick()
+        # what the later stages need from the QUERIES alone is started first: the stage-2 query forward runs beside
+        # stage 1's sweep of the corpus, stage 3's query tokens are ready when its pairs are assembled
+        for st in (self.stage2, self.stage3):
+            if hasattr(st, "prefetch_queries"):
+                st.prefetch_queries(queries)
         got = self._arrays_stage1(queries)
         if got is None:
             return None
@@ -373,18 +378,20 @@ class RetrievalPipeline:
         (pos2, sc2, pos3, sc3 as host arrays, stage-2 seconds, stage-3 seconds) or None."""
         import torch
         t = self._tick()
-        r2 = self.stage2.rescore_arrays(queries, ids1_dev)
+        r2 = self.stage2.rescore_arrays(queries, ids1_dev, lazy=True)
         if r2 is None:
             return None
-        pos2, sc2 = r2
+        pos2, sc2, bad2 = r2
         ids2_dev = torch.gather(ids1_dev.to(pos2.device), 1, pos2)
         t2 = (self._tick() - t) if t is not None else None
         t = self._tick()
-        r3 = self.stage3.rerank_arrays(queries, ids2_dev)
+        r3 = self.stage3.rerank_arrays(queries, ids2_dev, lazy=True)
         if r3 is None:
             return None
-        pos3, sc3 = r3
+        pos3, sc3, bad3 = r3
         out = (pos2.cpu().numpy(), sc2.cpu().numpy(), pos3.cpu().numpy(), sc3.cpu().numpy())
+        if bool(bad2) or bool(bad3):     # a candidate outside the token store / id cache (looked at only now: the copies
+            return None                  # above were the first time the host waited for the GPU since stage 3's batch plan)
         t3 = (self._tick() - t) if t is not None else None
         return out + (t2, t3)
 

@@ -482,12 +482,17 @@ class Stage1Retriever:
         n = int(self.faiss_index.ntotal)
         if top_k > n or n != len(self.documents):
             return None
+        fuse = self.config.enable_bm25 and self.bm25_index is not None
         if self._device_path():
-            D, I = self.faiss_index.search(self._normalized_query_tensor(list(queries)), top_k)
+            qt = self._normalized_query_tensor(list(queries))
+            if not fuse and hasattr(self.faiss_index, "search_in_stream_order"):
+                D, I = self.faiss_index.search_in_stream_order(qt, top_k)   # (ids stay on the GPU for stage 2: no wait here)
+            else:
+                D, I = self.faiss_index.search(qt, top_k)
         else:
             D, I = self.faiss_index.search(self._normalize_embeddings(self._encode_batch(list(queries))), top_k)
             D, I = torch.as_tensor(D), torch.as_tensor(I)
-        if not (self.config.enable_bm25 and self.bm25_index is not None):
+        if not fuse:
             return I, D
         bm25 = self.bm25_index
         if (self.config.fusion_method == "rrf" and I.is_cuda and getattr(self.config, "fuse_on_gpu", True)

@@ -164,7 +164,7 @@ class ColBERTScorer:
 
     def _forward(self, enc: Dict[str, torch.Tensor]) -> torch.Tensor:
         lengths = enc.get("lengths")
-        enc = {k: v for k, v in enc.items() if k != "lengths"}
+        enc = {k: v for k, v in enc.items() if k not in ("lengths", "lengths_host")}
         with torch.no_grad():
             if self.use_amp:
                 if getattr(self, "lean_forward", True):
@@ -186,6 +186,7 @@ class ColBERTScorer:
         out = self._model_inputs(enc)
         if lengths is not None:
             out["lengths"] = to_device_async(lengths, self.device)
+            out["lengths_host"] = [int(x) for x in lengths.tolist()]   # the same counts for the host: no .tolist() of a device tensor later
         return out
 
     def _pool_embeddings(self, embeddings: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
@@ -401,13 +402,28 @@ class ColBERTScorer:
                     self._graphed = GraphedForward(self.model, getattr(self.tokenizer, "pad_token_id", 0),
                                                    self._amp_dtype() if self.use_amp else None)
                 hidden = self._graphed(enc["input_ids"], enc["attention_mask"])
-                lens = enc["lengths"].tolist()
+                lens = enc["lengths_host"]
                 out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))
                 continue
             hidden = self._forward(enc)
-            lens = enc["attention_mask"].sum(dim=1).tolist()
+            lens = enc["lengths_host"] if "lengths_host" in enc else enc["attention_mask"].sum(dim=1).tolist()
             out.extend(hidden[j, :int(n), :] for j, n in enumerate(lens))
         return out
+
+    def prefetch_queries(self, queries: List[str]) -> None:
+        """Start the query forward of a coming score_arrays_partial / rescore_arrays call NOW: it does not depend on
+        stage 1, so the pipeline enqueues it before stage 1's search — its kernels run beside the corpus sweep and its
+        host side (tokenising, ~200 launches or a graph replay) no longer sits between stage 1's result and the MaxSim
+        launch.  Same forward, same values; used once, by the next call with the same queries."""
+        qs = list(queries)
+        self._q_prefetch = (qs, self.encode_queries_batch(qs))
+
+    def _query_embeddings(self, queries: List[str]) -> List[torch.Tensor]:
+        pre = getattr(self, "_q_prefetch", None)
+        self._q_prefetch = None
+        if pre is not None and pre[0] == list(queries):
+            return pre[1]
+        return self.encode_queries_batch(list(queries))
 
     def score_candidates_many(self, queries: List[str], candidates_list: List[List[Dict[str, Any]]]) -> List[List[float]]:
         """stage-2 scores for several queries: one query forward for all of them and, when every
@@ -465,44 +481,61 @@ class ColBERTScorer:
         self._slot_tab = (key, out)
         return out
 
-    def score_arrays_partial(self, queries: List[str], cand_ids: torch.Tensor) -> torch.Tensor:
+    def score_arrays_partial(self, queries: List[str], cand_ids: torch.Tensor, compact: Optional[bool] = None) -> torch.Tensor:
         """MaxSim scores float32 [B, C] of the candidates ``cand_ids`` int64 [B, C] that live in THIS process's token
         store; -inf everywhere else (ids outside the store's range, padding ids < 0).  One padded query forward, one
-        ts_maxsim_indexed_batch launch over the owned candidates (ragged per query), no collective.  With a
-        row-sharded store (parallel_pipeline.ShardedRetrievalPipeline) every candidate is owned by exactly one rank,
-        so an element-wise MAX over the ranks yields the complete score matrix."""
+        ts_maxsim_indexed_batch launch, no collective.  With a row-sharded store
+        (parallel_pipeline.ShardedRetrievalPipeline) every candidate is owned by exactly one rank, so an element-wise
+        MAX over the ranks yields the complete score matrix.
+
+        ``compact`` (default ``self.owner_compact``): True = score only the owned candidates (a ragged launch; the
+        per-query counts cost ONE host sync) — a rank of R owns ~1/R of them; False = score all B x C positions (a
+        position that is not owned reads document slot 0 and is masked afterwards): nothing here waits for the GPU,
+        which is what the single-process pipeline wants, where everything is owned anyway."""
         store = self.token_store
         dev = store.data.device if store.data is not None else cand_ids.device
         cand_ids = cand_ids.to(dev)
         B, C = cand_ids.shape
-        out = torch.full((B, C), float("-inf"), dtype=torch.float32, device=dev)
+        neg = float("-inf")
         got = self._slot_table(dev) if len(store) else None
         if got is None or B == 0 or C == 0:
-            return out
+            self._q_prefetch = None
+            return torch.full((B, C), neg, dtype=torch.float32, device=dev)
+        if compact is None:
+            compact = bool(getattr(self, "owner_compact", False))
         base, tab = got
         rel = cand_ids - base
         inside = (rel >= 0) & (rel < tab.numel())
         slots = torch.where(inside, tab[rel.clamp(0, tab.numel() - 1)], torch.full_like(rel, -1))
         owned = slots >= 0
-        counts = owned.sum(dim=1).tolist()            # the one host sync of the step: ragged candidate offsets
-        if sum(counts) == 0:
-            return out
-        q_embs = self.encode_queries_batch(list(queries))
+        if compact:
+            counts = owned.sum(dim=1).tolist()        # the one host sync of the step: ragged candidate offsets
+            if sum(counts) == 0:
+                self._q_prefetch = None
+                return torch.full((B, C), neg, dtype=torch.float32, device=dev)
+            sel = slots[owned]                        # row-major: grouped by query, stage-1 order inside a query
+        else:
+            counts = [C] * B
+            sel = slots.clamp(min=0).reshape(-1)
+        q_embs = self._query_embeddings(queries)
         starts_all, lens_all = store.device_tables()
         dt = store.data.dtype
         q_off, c_off = [0], [0]
         for e, c in zip(q_embs, counts):
             q_off.append(q_off[-1] + int(e.shape[0]))
             c_off.append(c_off[-1] + int(c))
-        q_packed = torch.cat([e.to(dt) for e in q_embs], 0).contiguous()
-        sel = slots[owned]                            # row-major: grouped by query, stage-1 order inside a query
+        q_packed = (q_embs[0].to(dt) if len(q_embs) == 1 else torch.cat([e.to(dt) for e in q_embs], 0)).contiguous()
         fn = self._maxsim_indexed_batch_fn
         if fn is None:
             from .index import maxsim_indexed_batch  # HIP kernel; raises without the library or a GPU
             fn = maxsim_indexed_batch
         flat = fn(q_packed, q_off, store.data, starts_all[sel], lens_all[sel], c_off, self.config.scoring_method)
-        out[owned] = flat.to(dev).to(torch.float32)
-        return out
+        flat = flat.to(dev).to(torch.float32)
+        if compact:
+            out = torch.full((B, C), neg, dtype=torch.float32, device=dev)
+            out[owned] = flat
+            return out
+        return torch.where(owned, flat.view(B, C), torch.full((), neg, dtype=torch.float32, device=dev))
 
     def keep_top_arrays(self, sc: torch.Tensor):
         """Stable descending sort of the score matrix [B, C] (= the reference's stable ``sort``, :293-297) ->
@@ -511,17 +544,21 @@ class ColBERTScorer:
         keep = min(self.config.top_k_candidates, sc.shape[1])
         return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
 
-    def rescore_arrays(self, queries: List[str], cand_ids: torch.Tensor):
+    def rescore_arrays(self, queries: List[str], cand_ids: torch.Tensor, lazy: bool = False):
         """rescore_many on arrays: ``cand_ids`` int64 [B, C] (CUDA; every row the stage-1 candidates of that
         query, in stage-1 order) -> (pos int64 [B, keep], scores float32 [B, keep]): the positions, in
         stage-1 order, of the ``top_k_candidates`` best candidates by stage-2 score — the stable descending
         sort of the reference (:293-297) — and their scores.  Everything stays on the GPU: one padded query
         forward, one MaxSim launch over the resident token store, one sort.  None if a candidate is not in
-        the store."""
+        the store — or, with ``lazy``, a third result: a 0-dim bool tensor that is true in that case (no host sync
+        here)."""
         if not len(self.token_store) or cand_ids.dim() != 2:
             return None
         sc = self.score_arrays_partial(queries, cand_ids)
-        if bool(torch.isinf(sc).any()):               # (a MaxSim score is a mean of cosines: never infinite)
+        bad = torch.isinf(sc).any()                   # (a MaxSim score is a mean of cosines: never infinite)
+        if lazy:                                      # the caller looks at `bad` when it copies the results out anyway
+            return self.keep_top_arrays(sc) + (bad,)
+        if bool(bad):
             return None
         return self.keep_top_arrays(sc)
 

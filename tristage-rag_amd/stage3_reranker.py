@@ -209,12 +209,22 @@ class CrossEncoderReranker:
         self._pairs_usable = True
         return True
 
-    def raw_arrays_partial(self, queries: List[str], doc_ids: torch.Tensor) -> torch.Tensor:
+    def prefetch_queries(self, queries: List[str]) -> None:
+        """Tokenise the queries of a coming rerank_arrays / raw_arrays_partial call now (host work that needs nothing
+        from stages 1 and 2: the pipeline does it while the GPU is busy with them)."""
+        pa = getattr(self, "_pairs", None)
+        if pa is not None and getattr(self, "_pairs_usable", False):
+            qs = list(queries)
+            self._q_prefetch = (qs, [pa.ids_of(q) for q in qs])
+
+    def raw_arrays_partial(self, queries: List[str], doc_ids: torch.Tensor, compact: Optional[bool] = None) -> torch.Tensor:
         """Activated cross-encoder scores float32 [B, C] of the pairs (queries[q], document doc_ids[q, j]) whose
         document lives in THIS process's token-id cache; -inf everywhere else.  The (query, document) inputs are
         assembled from cached token ids on the GPU with the tokenizer's own truncation and run through the
         cross-encoder in length-sorted batches of ``many_batch_size`` pairs (packed when the written-out forward
-        takes them); no collective.  With a row-sharded cache every pair is owned by exactly one rank."""
+        takes them); no collective.  With a row-sharded cache every pair is owned by exactly one rank.
+        ``compact`` (default ``self.owner_compact``): True = only the owned pairs run (their count is a host sync);
+        False = all B x C pairs run, a pair whose document is not cached reads slot 0 and is masked afterwards."""
         pa = getattr(self, "_pairs", None)
         dev = torch.device(self.model.device) if hasattr(self.model, "device") else doc_ids.device
         doc_ids = doc_ids.to(dev)
@@ -226,13 +236,24 @@ class CrossEncoderReranker:
         flat_ids = doc_ids.reshape(-1)
         owned = (flat_ids >= base) & (flat_ids < base + len(pa))
         whole = B * C
-        idx = torch.nonzero(owned).flatten()          # positions (row-major) of the owned pairs
-        P = int(idx.numel())                          # host sync (the plan below has one anyway)
-        if P == 0:
-            return raw_full.view(B, C)
-        q_ids = [pa.ids_of(q) for q in queries]
-        pair_q = torch.div(idx, C, rounding_mode="floor")
-        plan = pa.plan(q_ids, pair_q, flat_ids[idx] - base, dev)
+        if compact is None:
+            compact = bool(getattr(self, "owner_compact", False))
+        if compact:
+            idx = torch.nonzero(owned).flatten()      # positions (row-major) of the owned pairs
+            P = int(idx.numel())                      # host sync
+            if P == 0:
+                self._q_prefetch = None
+                return raw_full.view(B, C)
+            pair_q = torch.div(idx, C, rounding_mode="floor")
+            pair_slot = flat_ids[idx] - base
+        else:
+            idx, P = None, whole
+            pair_q = torch.arange(B, device=dev).repeat_interleave(C)
+            pair_slot = (flat_ids - base).clamp(0, len(pa) - 1)
+        pre = getattr(self, "_q_prefetch", None)
+        self._q_prefetch = None
+        q_ids = pre[1] if pre is not None and pre[0] == list(queries) else [pa.ids_of(q) for q in queries]
+        plan = pa.plan(q_ids, pair_q, pair_slot, dev)
         order = torch.argsort(plan["total"], descending=True, stable=True)
         raw = torch.empty((P,), dtype=torch.float32, device=dev)
         wm = max(int(getattr(self.config, "many_width_multiple", 1) or 1), 1)
@@ -260,6 +281,8 @@ class CrossEncoderReranker:
             enc = pa.batch(plan, sel, width=int(widths[j]))
             lg = self.model.logits_graphed(enc) if graph_one or (P <= bs and P == whole) else None   # one query's pairs: graph replay if enabled
             raw[sel] = self.model.activate(lg if lg is not None else self.model.logits_from_ids(enc)).reshape(-1)
+        if idx is None:
+            return torch.where(owned, raw, raw_full).view(B, C)
         raw_full[idx] = raw
         return raw_full.view(B, C)
 
@@ -274,7 +297,7 @@ class CrossEncoderReranker:
         keep = min(self.config.top_k_final, raw.shape[1])
         return pos[:, :keep].contiguous(), srt[:, :keep].contiguous()
 
-    def rerank_arrays(self, queries: List[str], doc_ids: torch.Tensor):
+    def rerank_arrays(self, queries: List[str], doc_ids: torch.Tensor, lazy: bool = False):
         """rerank_many on arrays: doc_ids int64 [B, C] (CUDA; row q = the stage-2 list of query q, in stage-2
         order) -> (pos int64 [B, keep], scores float64 [B, keep]): positions in stage-2 order of the
         ``top_k_final`` best by stage-3 score (min-max normalised per query like reference :212-228, stable
@@ -286,7 +309,10 @@ class CrossEncoderReranker:
         if B == 0 or C == 0:
             return None
         raw = self.raw_arrays_partial(queries, doc_ids)
-        if bool(torch.isinf(raw).any()):              # a document outside the id cache
+        bad = torch.isinf(raw).any()                  # a document outside the id cache
+        if lazy:                                      # third result: 0-dim bool tensor, looked at by the caller (no sync here)
+            return self.finish_arrays(raw) + (bad,)
+        if bool(bad):
             return None
         return self.finish_arrays(raw)
 
