@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--step-events", choices=["auto", "on", "off"], default="auto",
                     help="one HIP event per timed step on the submitting stream -> ms_per_step_min/max "
                          "(a few microseconds each in-stream).  auto: on for N=1, off for N>1")
+    ap.add_argument("--dump-steps", action="store_true",
+                    help="diagnostic: the per-step event intervals (ms) and the steps at which the collective finish() ran, "
+                         "as config.step_ms / config.finish_at")
     ap.add_argument("--no-encode-leg", action="store_true",
                     help="skip the secondary leg (bi-encoder forward of the 64 query texts + the same search)")
     ap.add_argument("--no-pipeline-leg", action="store_true",
@@ -431,9 +434,20 @@ def main():
         # the query tensors were materialised (and synchronised) before the loop
         return index.search(queries[i % len(queries)], args.k, async_=True, inputs_ready=pipeline)
 
+    finish_at = []
+
     def finish():
         if not args.sync:
             index.finish()
+
+    if args.dump_steps and hasattr(index, "_exchange_and_merge"):   # note when the wrapper's own (collective) finish() runs
+        _wrapped_finish = index.finish
+
+        def _noting_finish():
+            finish_at.append(len(finish_at_steps))
+            return _wrapped_finish()
+        finish_at_steps = []
+        index.finish = _noting_finish
 
     if args.submit_stream == "side" or (args.submit_stream == "auto" and pipeline):
         side = torch.cuda.Stream(device=device)
@@ -462,6 +476,8 @@ def main():
     if evs:
         evs[0].record()
     for i in range(args.steps):
+        if args.dump_steps and hasattr(index, "_exchange_and_merge"):
+            finish_at_steps.append(i)
         D, I = step(i)
         if evs:
             evs[i + 1].record()   # on the submitting stream, which every batch's result is ordered on
@@ -576,7 +592,8 @@ def main():
                        "search_path": info["path"] + (" (one launch: query image + thresholds + scan+filter)"
                                                       if info.get("one_launch") else ""),
                        "max_candidates_per_query": info["max_candidates"],
-                       "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]}},
+                       "phase_ms_per_step": {p: round(v[0] / max(v[1], 1), 4) for p, v in tm.items() if v[1]},
+                       **({"step_ms": [round(x, 3) for x in step_ms], "finish_at": finish_at} if args.dump_steps else {})},
             "roofline": roof,
             "secondary": enc_leg,
         }

@@ -223,6 +223,8 @@ class _CountingAsyncIndex:
     """OracleIndex with the asynchronous protocol of FlatIPIndex as far as the wrapper sees it: room for 60 passes
     of <= 32 queries between finish() calls, counted only for searches that actually ran on this rank."""
 
+    PENDING_PASSES = 60
+
     def __init__(self, d):
         from doubles import OracleIndex
         self._o = OracleIndex(d)

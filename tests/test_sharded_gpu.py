@@ -102,7 +102,7 @@ def _two_rank_worker(rank, world, port, out_dir):
         qs = [torch.from_numpy(mk(64, d, seed=40 + i, dtype="f16")).cuda().half() for i in range(3)]
         sync = [idx.search(q, k) for q in qs]
         torch.cuda.synchronize()
-        outs = [idx.search(qs[i % 3], k, async_=True, inputs_ready=True) for i in range(55)]   # > 48: finish() mid-way
+        outs = [idx.search(qs[i % 3], k, async_=True, inputs_ready=True) for i in range(130)]   # > 120 batches: a collective finish() mid-way
         idx.finish()
         for i, (Da, Ia) in enumerate(outs):
             assert torch.equal(Ia, sync[i % 3][1]) and torch.equal(Da, sync[i % 3][0]), i
@@ -155,7 +155,8 @@ def test_sharded_numpy_call_and_odd_k_on_the_real_index():
 def test_sharded_async_repairs_survive_many_pending_batches():
     """with more asynchronous batches in flight than the local index tracks, a batch whose fused
     filter failed (20 000 exact ties overflow the candidate list) must still be re-exchanged after its local
-    repair.  RCCL world of one with the exchange forced on; 80 batches, every other one failing; odd B*k too."""
+    repair.  RCCL world of one with the exchange forced on; 260 batches (the wrapper finishes collectively every 120),
+    every other one failing; odd B*k too."""
     import torch
     import torch.distributed as dist
     from tristage_rag_amd.sharded import ShardedFlatIPIndex
@@ -183,7 +184,7 @@ def test_sharded_async_repairs_survive_many_pending_batches():
         check_topk(Db.cpu().numpy(), Ib.cpu().numpy(), corpus, bad_q, k)
         torch.cuda.synchronize()
         for ready in (False, True):
-            outs = [idx.search(qb if i % 2 else qa, k, async_=True, inputs_ready=ready) for i in range(80)]
+            outs = [idx.search(qb if i % 2 else qa, k, async_=True, inputs_ready=ready) for i in range(260)]
             idx.finish()
             for i, (D, I) in enumerate(outs):
                 wd, wi = (Db, Ib) if i % 2 else (Da, Ia)
@@ -191,9 +192,9 @@ def test_sharded_async_repairs_survive_many_pending_batches():
         # the plain index: its own automatic finish() must hand the repaired tickets to the next finish()
         li = FlatLocal = idx.local_index
         li.auto_finish = True
-        outs = [li.search(qb if i % 2 else qa, k, async_=True) for i in range(70)]
+        outs = [li.search(qb if i % 2 else qa, k, async_=True) for i in range(250)]   # > PENDING_PASSES: one internal finish()
         redone = li.finish()
-        assert len(redone) == 35, redone
+        assert len(redone) == 125, redone
     finally:
         dist.destroy_process_group()
 

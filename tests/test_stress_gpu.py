@@ -55,7 +55,7 @@ def test_long_pipelined_stream_is_deterministic():
     torch.cuda.synchronize()
     want = [idx.search(q, 500) for q in qs]
     for rep in range(4):
-        outs = [idx.search(qs[i % 8], 500, async_=True, inputs_ready=True) for i in range(120)]   # > one finish() window
+        outs = [idx.search(qs[i % 8], 500, async_=True, inputs_ready=True) for i in range(150)]   # > one finish() window (240 passes of 32)
         idx.finish()
         for i, (D, I) in enumerate(outs):
             assert torch.equal(I, want[i % 8][1]) and torch.equal(D, want[i % 8][0]), (rep, i)

@@ -78,7 +78,7 @@ void release(DevBuf& b) {
 }  // namespace
 #define TS_NPHASE 8
 #define TS_NSETS 4         // workspace sets = synchronous searches that may run at once on one handle
-#define TS_ASYNC_SLOTS 256
+#define TS_ASYNC_SLOTS 1024   // report slots; at most a quarter of them (256 passes) may belong to unfinished asynchronous searches
 #define TS_SLOT_WORDS 80   // 64 counts + status word, padded
 namespace {
 // tuning constants of the filter path (DESIGN.md "threshold sampling")

@@ -57,6 +57,7 @@ class FlatIPIndex:
     """Exact inner-product index resident in MI355X HBM."""
 
     supports_out = True  # search(..., out=(D, I)) writes into caller tensors
+    PENDING_PASSES = 240  # passes of <= 32 queries that may wait for finish() (the library tracks 256)
 
     def __init__(self, d: int, dtype: str = "f32", device: int = 0):
         if dtype not in _NAME_TO_DTYPE:
@@ -243,7 +244,7 @@ class FlatIPIndex:
 
     def pending_room(self, n_queries: int) -> int:
         """>= 0 while another asynchronous search of `n_queries` queries fits before a finish()."""
-        return 60 - self._pending_passes - (int(n_queries) + 31) // 32
+        return self.PENDING_PASSES - self._pending_passes - (int(n_queries) + 31) // 32
 
     def finish(self):
         """Complete every asynchronous search: one stream sync, then the (rare)
@@ -251,10 +252,10 @@ class FlatIPIndex:
         exact dense path, in place.  Returns the tickets that were repeated since the
         caller's previous finish() (including those an internal finish() — issued when
         too many searches were pending — had to repeat)."""
-        failed = (ctypes.c_int64 * 64)()
+        failed = (ctypes.c_int64 * 256)()
         nf = ctypes.c_int32(0)
         _lib.check(self._lib.ts_index_finish(self._h, ctypes.c_void_p(_stream_ptr(self.device)) if
-                                             _stream_ptr(self.device) else None, failed, 64, ctypes.byref(nf)))
+                                             _stream_ptr(self.device) else None, failed, 256, ctypes.byref(nf)))
         redone = []
         for i in range(nf.value):
             q, k, D, I = self._pending[int(failed[i])]
