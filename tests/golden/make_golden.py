@@ -68,6 +68,21 @@ def main() -> None:
         "search_top5": [[[int(i), float(s)] for i, s in bm.search(q, 5)] for q in queries],
     }
 
+    # ---- BM25 after a SECOND add_documents: the reference re-fits on the whole corpus but never clears doc_freqs /
+    # doc_lens (src/stage1_retriever.py:56-80, called at :316-322), so the statistics of the first batch are counted
+    # twice and documents added later are scored with the term frequencies of earlier ones.  Captured as it is, for
+    # the build's `bm25_refit_compat` switch.
+    bm2 = BM25Index()
+    first, second = docs[:3], docs[3:] + ["Attention is all you need: transformers for neural machine translation."]
+    bm2.fit(list(first))
+    bm2.fit(list(first) + list(second))
+    kat["bm25_refit"] = {
+        "first": first, "second": second, "queries": queries,
+        "idf": {k: bm2.idf[k] for k in sorted(bm2.idf)},
+        "avg_doc_len": bm2.avg_doc_len, "doc_lens": bm2.doc_lens, "corpus_size": bm2.corpus_size,
+        "search_top6": [[[int(i), float(s)] for i, s in bm2.search(q, 6)] for q in queries],
+    }
+
     # ---- fusion (src/stage1_retriever.py:326-366)
     s1 = Stage1Retriever.__new__(Stage1Retriever)
     s1.config = Stage1Config()

@@ -22,6 +22,20 @@ def test_gpu_bm25_matches_reference_outputs():
     idx.close()
 
 
+def test_gpu_bm25_refit_compat_matches_reference_outputs():
+    """The reference's statistics after a SECOND fit (appended lists), on the HIP scorer: bit for bit."""
+    from tristage_rag_amd.stage1_retriever import BM25Index
+    b = KAT["bm25_refit"]
+    idx = BM25Index(gpu_device=0, refit_compat=True)
+    idx.fit(list(b["first"]))
+    idx.fit(list(b["first"]) + list(b["second"]))
+    for q, want in zip(b["queries"], b["search_top6"]):
+        got = idx.search(q, 6)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        assert [s for _, s in got] == [s for _, s in want]
+    idx.close()
+
+
 def test_gpu_bm25_equals_host_bm25_on_a_larger_corpus():
     from tristage_rag_amd.stage1_retriever import BM25Index
     rng = np.random.default_rng(5)

@@ -67,6 +67,32 @@ def test_bm25_matches_reference():
     assert idx.corpus_size == 6 and len(idx.doc_freqs) == 6
 
 
+def test_bm25_refit_compat_matches_reference_after_a_second_add():
+    """`bm25_refit_compat` reproduces the reference's statistics after a second add_documents — its fit()
+    appends to the previous fit's lists (src/stage1_retriever.py:56-80, re-fit at :316-322): df and the average length
+    count the first batch twice and document i is scored with list entry i.  Pinned by the reference's own outputs;
+    without the switch the index is rebuilt (= the reference after ONE add of the same corpus)."""
+    b = KAT["bm25_refit"]
+    first, allv = list(b["first"]), list(b["first"]) + list(b["second"])
+    idx = BM25Index(refit_compat=True)
+    idx.fit(first)
+    idx.fit(allv)
+    assert idx.corpus_size == b["corpus_size"] and idx.doc_lens == b["doc_lens"] and idx.avg_doc_len == b["avg_doc_len"]
+    assert {k: idx.idf[k] for k in sorted(idx.idf)} == pytest.approx(b["idf"], rel=1e-15)
+    for q, want in zip(b["queries"], b["search_top6"]):
+        got = idx.search(q, 6)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        assert [s for _, s in got] == pytest.approx([s for _, s in want], rel=1e-15)
+        for i, s_ in want:
+            assert idx.score(q, i) == pytest.approx(s_, rel=1e-15)
+    plain, once = BM25Index(), BM25Index()
+    plain.fit(first)
+    plain.fit(allv)
+    once.fit(allv)
+    assert plain.idf == once.idf and plain.doc_lens == once.doc_lens       # the default re-fit rebuilds
+    assert any(plain.search(q, 6) != [tuple(x) for x in w] for q, w in zip(b["queries"], b["search_top6"]))
+
+
 def test_fusion_matches_reference(encoder, tmp_path):
     s1 = _stage1(encoder, tmp_path)
     for case in KAT["fusion"]:

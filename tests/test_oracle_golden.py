@@ -25,6 +25,22 @@ def test_bm25_matches_reference():
         assert [s for _, s in got] == pytest.approx([s for _, s in want], rel=1e-15)
 
 
+def test_bm25_after_a_second_fit_matches_reference():
+    """The reference's fit() appends to the lists of the previous fit (src/stage1_retriever.py:56-80): the oracle keeps
+    that, and the reference's own outputs after fit(first) + fit(first + second) pin it."""
+    b = KAT["bm25_refit"]
+    idx = oracle.BM25Index()
+    idx.fit(list(b["first"]))
+    idx.fit(list(b["first"]) + list(b["second"]))
+    assert idx.doc_lens == b["doc_lens"] and idx.corpus_size == b["corpus_size"]
+    assert idx.avg_doc_len == b["avg_doc_len"]
+    assert {k: idx.idf[k] for k in sorted(idx.idf)} == pytest.approx(b["idf"], rel=1e-15)
+    for q, want in zip(b["queries"], b["search_top6"]):
+        got = idx.search(q, 6)
+        assert [i for i, _ in got] == [i for i, _ in want]
+        assert [s for _, s in got] == pytest.approx([s for _, s in want], rel=1e-15)
+
+
 def test_survey_known_answers():
     # SURVEY.md §8c, captured independently from the same reference functions
     idx = oracle.BM25Index()

@@ -298,22 +298,21 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         """Stages 2 and 3 of ALL queries on every rank, each rank scoring what it owns; two all-reduces."""
         if self.world_size == 1:
             return super()._arrays_stage23(queries, ids1_dev)
-        t = self._tick()
+        ma = self._tick()
         sc2_all = self._all_reduce_max(self.stage2.score_arrays_partial(queries, ids1_dev))
         bad = bool(torch.isinf(sc2_all).any())       # a candidate nobody owns: identical on every rank after the reduce
         if bad:
             return None
         pos2, sc2 = self.stage2.keep_top_arrays(sc2_all)
         ids2_dev = torch.gather(ids1_dev.to(pos2.device), 1, pos2)
-        t2 = (self._tick() - t) if t is not None else None
-        t = self._tick()
+        mb = self._tick()
         raw3 = self._all_reduce_max(self.stage3.raw_arrays_partial(queries, ids2_dev))
         if bool(torch.isinf(raw3).any()):
             return None
         pos3, sc3 = self.stage3.finish_arrays(raw3)
+        mc = self._tick()
         out = (pos2.cpu().numpy(), sc2.cpu().numpy(), pos3.cpu().numpy(), sc3.cpu().numpy())
-        t3 = (self._tick() - t) if t is not None else None
-        return out + (t2, t3)
+        return out + (self._span(ma, mb), self._span(mb, mc))
 
     def search_many(self, queries: List[str], top_k: Optional[int] = None) -> List[Dict[str, Any]]:
         """Batched search over R ranks; every rank returns every query's records.  Array path (token store + id

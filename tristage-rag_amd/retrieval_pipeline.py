@@ -66,6 +66,7 @@ class PipelineConfig:
     # ---- additive (MI355X) ----
     stage1_index_dtype: str = "f32"          # corpus storage on the GPU: f32 | f16 | bf16
     stage1_bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM, HIP scoring; None = when a GPU is used
+    stage1_bm25_refit_compat: bool = False     # BM25 after a second add_documents as the reference computes it (appended statistics)
     stage2_cache_document_embeddings: bool = False
     stage2_precompute_document_embeddings: bool = False  # token store filled by add_documents
     use_hip_graphs: bool = False             # query forwards of stages 1/2 and a query's stage-3 pairs replayed from HIP graphs
@@ -176,6 +177,7 @@ class RetrievalPipeline:
                 enable_bm25=c.stage1_enable_bm25, bm25_top_k=c.stage1_bm25_top_k,
                 fusion_method=c.stage1_fusion_method, use_fp16=c.stage1_use_fp16,
                 index_dtype=c.stage1_index_dtype, bm25_on_gpu=c.stage1_bm25_on_gpu,
+                bm25_refit_compat=c.stage1_bm25_refit_compat,
                 use_hip_graph=c.use_hip_graphs, index_batch_size=c.stage1_index_batch_size, amp_dtype=c.amp_dtype))
             self.logger.info("Stage 1 initialized")
             self.stage2 = ColBERTScorer(Stage2Config(
@@ -327,35 +329,56 @@ class RetrievalPipeline:
         if not self._arrays_ready():
             return None
         n = len(queries)
-        total_start = t = self._tick()
+        m0 = self._tick()
         # what the later stages need from the QUERIES alone is started first: the stage-2 query forward runs beside
         # stage 1's sweep of the corpus, stage 3's query tokens are ready when its pairs are assembled
         for st in (self.stage2, self.stage3):
             if hasattr(st, "prefetch_queries"):
                 st.prefetch_queries(queries)
+        mp = self._tick()
         got = self._arrays_stage1(queries)
         if got is None:
             return None
         ids1_dev, sc1 = got
-        t1 = (self._tick() - t) / n if t is not None else None
+        m1 = self._tick()
         later = self._arrays_stage23(queries, ids1_dev)
         if later is None:
             return None
-        pos2_h, sc2_h, pos3_h, sc3_h, t2s, t3s = later
-        t2 = t2s / n if t2s is not None else None
+        pos2_h, sc2_h, pos3_h, sc3_h, t2s, t3s = later       # (the host has waited for the GPU in there: marks are complete)
+        t1 = self._span(mp, m1)
+        t1 = t1 / n if t1 is not None else None
+        pre = self._span(m0, mp)                              # the prefetched query work belongs to stages 2 / 3
+        t2 = (t2s + (pre or 0.0)) / n if t2s is not None else None
         t3 = t3s / n if t3s is not None else None
         ids1_h = ids1_dev.cpu().numpy()
         sc1_h = sc1.cpu().numpy() if hasattr(sc1, "cpu") else sc1
-        total = (time.time() - total_start) / n if total_start is not None else None
+        total = (time.time() - m0[0]) / n if m0 is not None else None
         return self._records_from_arrays(queries, top_k, ids1_h, sc1_h, pos2_h, sc2_h, pos3_h, sc3_h, t1, t2, t3, total)
 
-    def _tick(self) -> Optional[float]:
+    def _tick(self):
+        """A stage boundary of the array path: (host time, HIP event recorded on the current stream) — NOT a
+        synchronisation.  Round 2 synchronised the device at every boundary (six times per search): correct stage
+        times, but the GPU drained six times per query and `search()` paid 1.5 ms of its 5.5 ms for it.  The stage
+        times are now the GPU-side intervals between the events, read after the call's results have been copied
+        out (`_span`); the total stays wall-clock."""
         if not self.config.enable_timing:
             return None
         import torch
+        ev = None
         if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        return time.time()
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        return (time.time(), ev)
+
+    @staticmethod
+    def _span(a, b) -> Optional[float]:
+        """Seconds between two _tick() marks (device time when both carry an event, else host time)."""
+        if a is None or b is None:
+            return None
+        if a[1] is not None and b[1] is not None:
+            b[1].synchronize()
+            return a[1].elapsed_time(b[1]) / 1e3
+        return b[0] - a[0]
 
     def _arrays_ready(self) -> bool:
         s1, s2, s3 = self.stage1, self.stage2, self.stage3
@@ -377,23 +400,22 @@ class RetrievalPipeline:
         """Stages 2 and 3 of `queries` (row i of ids1_dev = the stage-1 ids of queries[i]) ->
         (pos2, sc2, pos3, sc3 as host arrays, stage-2 seconds, stage-3 seconds) or None."""
         import torch
-        t = self._tick()
+        ma = self._tick()
         r2 = self.stage2.rescore_arrays(queries, ids1_dev, lazy=True)
         if r2 is None:
             return None
         pos2, sc2, bad2 = r2
         ids2_dev = torch.gather(ids1_dev.to(pos2.device), 1, pos2)
-        t2 = (self._tick() - t) if t is not None else None
-        t = self._tick()
+        mb = self._tick()
         r3 = self.stage3.rerank_arrays(queries, ids2_dev, lazy=True)
         if r3 is None:
             return None
         pos3, sc3, bad3 = r3
+        mc = self._tick()
         out = (pos2.cpu().numpy(), sc2.cpu().numpy(), pos3.cpu().numpy(), sc3.cpu().numpy())
         if bool(bad2) or bool(bad3):     # a candidate outside the token store / id cache (looked at only now: the copies
             return None                  # above were the first time the host waited for the GPU since stage 3's batch plan)
-        t3 = (self._tick() - t) if t is not None else None
-        return out + (t2, t3)
+        return out + (self._span(ma, mb), self._span(mb, mc))
 
     def _records_from_arrays(self, queries, top_k, ids1_h, sc1_h, pos2_h, sc2_h, pos3_h, sc3_h, t1, t2, t3, total):
         s1 = self.stage1

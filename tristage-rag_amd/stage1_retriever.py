@@ -62,6 +62,8 @@ class Stage1Config:
     bm25_on_gpu: Optional[bool] = None  # BM25 postings in HBM + HIP scoring kernels; None = whenever
                                         # the HIP index is in use (a GPU is present)
     use_hip_graph: bool = False  # replay single-query encoder forwards from HIP graphs
+    bm25_refit_compat: bool = False  # BM25 statistics after a SECOND add_documents exactly as the reference computes them
+                                     # (its fit() appends to the previous fit's lists; see BM25Index)
 
 
 def amp_torch_dtype(name: str):
@@ -79,10 +81,16 @@ class BM25Index:
     """BM25 (k1=1.2, b=0.75) with the reference's tokenizer and idf
     (reference src/stage1_retriever.py:35-112), over an inverted index."""
 
-    def __init__(self, k1: float = 1.2, b: float = 0.75, gpu_device: Optional[int] = None):
+    def __init__(self, k1: float = 1.2, b: float = 0.75, gpu_device: Optional[int] = None, refit_compat: bool = False):
         self.k1 = k1
         self.b = b
         self.gpu_device = gpu_device   # None: score on the host; int: HIP kernels on that GPU
+        # refit_compat: reproduce what the reference's BM25Index does when fit() is called AGAIN (every add_documents
+        # after the first, src/stage1_retriever.py:316-322): its fit() appends to doc_freqs / doc_lens instead of
+        # rebuilding them (:56-80), so the statistics of earlier fits are counted again in df and the average length,
+        # and document i is scored with list entry i — for documents added later that is an EARLIER document's term
+        # frequencies.  Off (default): fit() rebuilds, i.e. the scores the reference gives after ONE add_documents.
+        self.refit_compat = bool(refit_compat)
         self._gpu = None
         import threading
         self._gpu_lock = threading.Lock()   # the GPU handle serves one caller at a time
@@ -105,29 +113,36 @@ class BM25Index:
     def fit(self, documents: Sequence[str]) -> None:
         self.documents = list(documents)
         self.corpus_size = len(self.documents)
-        self.doc_freqs, self.doc_lens, self.idf = [], [], {}
-        self.vocabulary = set()
-        post_d: Dict[str, List[int]] = defaultdict(list)
-        post_tf: Dict[str, List[int]] = defaultdict(list)
-        for i, doc in enumerate(self.documents):
+        keep = self.refit_compat and bool(self.doc_freqs)
+        if not keep:
+            self.doc_freqs, self.doc_lens = [], []
+        self.idf = {}
+        for doc in self.documents:
             tf: Dict[str, int] = defaultdict(int)
             toks = self.tokenize(doc)
             for t in toks:
                 tf[t] += 1
-            self.doc_freqs.append(tf)
+            self.doc_freqs.append(tf)         # (refit_compat: BEHIND the entries of the earlier fits, like the reference)
             self.doc_lens.append(len(toks))
-            for t, c in tf.items():
-                post_d[t].append(i)
-                post_tf[t].append(c)
-        self.vocabulary = set(post_d)
-        self.avg_doc_len = sum(self.doc_lens) / self.corpus_size if self.corpus_size > 0 else 0
         n = self.corpus_size
-        for t, ds in post_d.items():
-            df = len(ds)
-            self.idf[t] = math.log((n - df + 0.5) / (df + 0.5) + 1.0)
+        # document i is scored with list entry i (reference score(), :83-101); df and the average length run over
+        # ALL entries (:76-80) — the same thing unless refit_compat kept entries of earlier fits
+        post_d: Dict[str, List[int]] = defaultdict(list)
+        post_tf: Dict[str, List[int]] = defaultdict(list)
+        df: Dict[str, int] = defaultdict(int)
+        for i, tf in enumerate(self.doc_freqs):
+            for t, c in tf.items():
+                df[t] += 1
+                if i < n:
+                    post_d[t].append(i)
+                    post_tf[t].append(c)
+        self.vocabulary = set(df)
+        self.avg_doc_len = sum(self.doc_lens) / n if n > 0 else 0
+        for t, d_ in df.items():
+            self.idf[t] = math.log((n - d_ + 0.5) / (d_ + 0.5) + 1.0)
         self._postings = {t: (np.asarray(post_d[t], dtype=np.int64), np.asarray(post_tf[t], dtype=np.float64))
                           for t in post_d}
-        lens = np.asarray(self.doc_lens, dtype=np.float64)
+        lens = np.asarray(self.doc_lens[:n], dtype=np.float64)
         self._len_norm = (self.k1 * (1 - self.b + self.b * lens / self.avg_doc_len)
                           if self.avg_doc_len else np.zeros_like(lens))
         if self.gpu_device is not None:
@@ -382,7 +397,8 @@ class Stage1Retriever:
                 self.faiss_index.add(embeddings)
         if self.config.enable_bm25:
             if self.bm25_index is None:
-                self.bm25_index = BM25Index(gpu_device=self._bm25_device())
+                self.bm25_index = BM25Index(gpu_device=self._bm25_device(),
+                                            refit_compat=getattr(self.config, "bm25_refit_compat", False))
             self.bm25_index.fit(self.documents)
         self.logger.info(f"Documents added successfully. Total documents: {len(self.documents)}")
 
