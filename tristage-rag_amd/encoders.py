@@ -738,8 +738,10 @@ class PairAssembler:
         for i, x in enumerate(q_ids):
             x = x[: self.max_length]
             qtab[i, : len(x)] = torch.as_tensor(x, dtype=torch.int32)
-        qtab = qtab.to(device)
-        qlen = torch.as_tensor([len(x) for x in q_ids], dtype=torch.int64, device=device)
+        # (through pinned memory: a pageable host-to-device copy waits for everything already queued on the stream —
+        # here the whole of stages 1 and 2 — before the host may go on planning stage 3)
+        qtab = to_device_async(qtab, device)
+        qlen = to_device_async(torch.as_tensor([len(x) for x in q_ids], dtype=torch.int64), device)
         budget = self.max_length - len(self.prefix) - len(self.middle) - len(self.suffix)
         la, lb = self._longest_first(qlen[pair_q], dlen[pair_slot].to(torch.int64), budget, self.rule)
         total = la + lb + (len(self.prefix) + len(self.middle) + len(self.suffix))
