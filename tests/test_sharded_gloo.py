@@ -204,6 +204,41 @@ def _pipeline_worker(rank, world, port, out_dir):
         a4 = par4.search_many(["omega omega omega sigma"])[0]
         assert [r["doc_id"] for r in a4["results"]] == [r["doc_id"] for r in a3["results"]]
         assert [r["document"] for r in a4["results"]] == [skew[r["doc_id"]] for r in a4["results"]]
+        # ... also with the reference's default BM25 + RRF: the lexical index is sharded too (local postings, corpus-wide
+        # statistics): BM25 lists bit-identical to one index over the whole corpus, and the pipeline's records equal
+        from tristage_rag_amd.stage1_retriever import BM25Index
+        par5 = build_arrays(ShardedRetrievalPipeline)
+        par5._merge_fn = oracle_merge
+        par5.add_documents_shard(docs[lo:hi], len(docs))
+        whole = BM25Index()
+        whole.fit(docs)
+        for q in qs + ["d7 d30 gpu", "zzzz"]:
+            assert par5.stage1.bm25_index.search(q, 12) == whole.search(q, 12), q        # float64 scores, bit for bit
+        many5 = par5.search_many(qs)
+        for a, b in zip(many5, ref2):
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
+                np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+        # per-rank persistence: every rank writes its shard (rows, token matrices, text), a fresh pipeline of the same
+        # world size loads it back without re-encoding the corpus rows
+        path = os.path.join(out_dir, "saved", "pipeline_index.pkl")
+        par5.save_index(path)
+        assert os.path.exists(os.path.join(out_dir, "saved", f"pipeline_index.shard{rank}of{world}.json"))
+        par6 = build_arrays(ShardedRetrievalPipeline)
+        par6._merge_fn = oracle_merge
+        encodes = []
+        orig_enc = par6.stage1._encode_batch
+        par6.stage1._encode_batch = lambda texts: (encodes.append(len(texts)), orig_enc(texts))[1]
+        par6.load_index(path)
+        assert sum(encodes) == 0                      # no document went through the bi-encoder again
+        assert len(par6.stage2.token_store) == hi - lo and par6.get_pipeline_info()["sharding"]["rows"] == [lo, hi]
+        many6 = par6.search_many(qs)
+        for a, b in zip(many6, many5):
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in a[stage]] == [r["doc_id"] for r in b[stage]], (a["query"], stage)
+                np.testing.assert_allclose([r[key] for r in a[stage]], [r[key] for r in b[stage]], atol=2e-5)
+                assert [r["document"] for r in a[stage]] == [r["document"] for r in b[stage]]
+        res.append([r["doc_id"] for r in many6[0]["results"]])
         json.dump(res, open(os.path.join(out_dir, f"res{rank}.json"), "w"))
     finally:
         dist.destroy_process_group()

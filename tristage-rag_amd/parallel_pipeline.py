@@ -33,9 +33,11 @@ sizes of BASELINE.json's configs[3] / [4].  Sharded with the rows, 8 GPUs hold
 ~15 M documents of that size and every stage's work splits 1/R as well (for a
 corpus whose relevant documents are spread over the shards).
 
-BM25 statistics need the whole corpus: with ``add_documents`` (every rank is given
-the full list) the BM25 index is replicated and fitted from that list; with
-``add_documents_shard`` (each rank is given only its rows) BM25 must be off.
+  BM25     its documents' postings, scored with the CORPUS-WIDE statistics (document
+           frequencies, count and average length all-gathered once at fit time):
+           bit-identical scores; per-shard top-k lists all-gathered and merged in the
+           reference's order (ShardedBM25).
+
 Every rank issues the same sequence of calls (the collectives are matched by
 construction: their cadence never depends on rank-local state).
 """
@@ -92,6 +94,83 @@ class ShardedList:
         raise ValueError("a row-sharded corpus is given in ONE add_documents call")
 
 
+class ShardedBM25:
+    """BM25 over a row-sharded corpus: every rank indexes ITS documents with the corpus-wide statistics (document
+    frequencies, document count and average length all-gathered once at fit time), so a document's score is bit for bit
+    the one reference src/stage1_retriever.py:83-101 gives it over the whole corpus; a query is scored on every shard
+    (HIP scorer when the local index lives on the GPU), the per-shard top-k lists (global ids) are all-gathered and
+    merged in the reference's order — score descending, ties by ascending id (its stable sort over ascending ids,
+    :103-112).  Same interface as BM25Index as far as Stage1Retriever uses it."""
+
+    def __init__(self, dist, group, world_size: int, rank: int, lo: int, gpu_device=None):
+        self._dist, self.group, self.world_size, self.rank, self.lo = dist, group, world_size, rank, int(lo)
+        self.local = BM25Index(gpu_device=gpu_device)
+        self.n_total = 0
+
+    def _exchange(self, df, total_len, n_docs):
+        parts: List[Any] = [None] * self.world_size
+        self._dist.all_gather_object(parts, (df, int(total_len), int(n_docs)), group=self.group)
+        g: Dict[str, int] = {}
+        tl = nd = 0
+        for d_, t_, n_ in parts:
+            for k, v in d_.items():
+                g[k] = g.get(k, 0) + int(v)
+            tl += t_
+            nd += n_
+        self.n_total = nd
+        return g, tl, nd
+
+    def fit(self, my_documents: Sequence[str]) -> None:
+        self.local.fit(my_documents, stats_exchange=self._exchange if self.world_size > 1 else None)
+        self.local.documents = []
+        if self.world_size == 1:
+            self.n_total = self.local.corpus_size
+
+    @property
+    def vocabulary(self):
+        return self.local.vocabulary
+
+    @property
+    def corpus_size(self) -> int:
+        return self.n_total
+
+    def _merge(self, ids: np.ndarray, scores: np.ndarray, k: int):
+        """ids int64 [nq, k_local] (global, -1 = nothing), scores float64 -> the global top-k of every query."""
+        R = self.world_size
+        nq, kl = ids.shape
+        if R > 1:
+            t = torch.empty((R, nq, kl, 2), dtype=torch.float64)
+            mine = torch.stack([torch.from_numpy(ids.astype(np.float64)), torch.from_numpy(scores)], dim=-1)   # ids < 2^53: exact
+            self._dist.all_gather_into_tensor(t.view(R, -1), mine.reshape(1, -1).contiguous(), group=self.group)
+            ids = t[..., 0].permute(1, 0, 2).reshape(nq, R * kl).numpy().astype(np.int64)
+            scores = t[..., 1].permute(1, 0, 2).reshape(nq, R * kl).numpy()
+        out = []
+        want = min(int(k), self.n_total)
+        for q in range(nq):
+            keep = ids[q] >= 0
+            i, s_ = ids[q][keep], scores[q][keep]
+            order = np.lexsort((i, -s_))[:want]            # score descending, then id ascending
+            out.append((i[order], s_[order]))
+        return out
+
+    def search_many_arrays(self, queries: Sequence[str], top_k: int = 10):
+        k = int(top_k)
+        kl = min(k, max(self.local.corpus_size, 0))
+        got = self.local.search_many_arrays(list(queries), kl) if kl > 0 else [(np.zeros(0, np.int64), np.zeros(0))] * len(queries)
+        ids = np.full((len(queries), k), -1, dtype=np.int64)
+        sc = np.zeros((len(queries), k), dtype=np.float64)
+        for q, (i, s_) in enumerate(got):
+            ids[q, : len(i)] = np.asarray(i, dtype=np.int64) + self.lo
+            sc[q, : len(i)] = s_
+        return self._merge(ids, sc, k)
+
+    def search_many(self, queries: Sequence[str], top_k: int = 10):
+        return [list(zip(i.tolist(), s_.tolist())) for i, s_ in self.search_many_arrays(queries, top_k)]
+
+    def search(self, query: str, top_k: int = 10):
+        return self.search_many([query], top_k)[0]
+
+
 class ShardedRetrievalPipeline(RetrievalPipeline):
     def __init__(self, config_path: Optional[str] = None, config: Optional[PipelineConfig] = None,
                  group=None):
@@ -130,29 +209,24 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         """Every rank passes the SAME full list; each keeps (encodes, tokenises, stores) only its rows."""
         n = len(documents)
         lo, hi = shard_bounds(n, self.world_size, self.rank)
-        self._add(list(documents[lo:hi]), None if metadata is None else list(metadata[lo:hi]), n, lo,
-                  all_documents=documents)
+        self._add(list(documents[lo:hi]), None if metadata is None else list(metadata[lo:hi]), n, lo)
 
     def add_documents_shard(self, my_documents: List[str], n_total: int,
                             metadata: Optional[List[Dict[str, Any]]] = None):
         """Each rank passes ONLY the documents of its own rows, shard_bounds(n_total, R, rank), in row order — the
-        ingestion call for corpora no single host should hold (configs[3]: 10 M documents).  BM25 needs corpus-wide
-        statistics and has to be off here."""
+        ingestion call for corpora no single host should hold (configs[3]: 10 M documents)."""
         lo, hi = shard_bounds(int(n_total), self.world_size, self.rank)
         if len(my_documents) != hi - lo:
             raise ValueError(f"rank {self.rank} of {self.world_size} owns rows [{lo}, {hi}) of {n_total}: expected "
                              f"{hi - lo} documents, got {len(my_documents)}")
-        self._add(list(my_documents), metadata, int(n_total), lo, all_documents=None)
+        self._add(list(my_documents), metadata, int(n_total), lo)
 
-    def _add(self, mine: List[str], my_meta, n: int, lo: int, all_documents) -> None:
+    def _add(self, mine: List[str], my_meta, n: int, lo: int) -> None:
         if self._indexed:
             raise ValueError("ShardedRetrievalPipeline takes the corpus in one add_documents call")
         if not self.stage1:
             self.initialize_stages()
         s1 = self.stage1
-        if s1.config.enable_bm25 and all_documents is None:
-            raise ValueError("BM25 needs corpus-wide statistics: use add_documents (full list on every rank) or "
-                             "set stage1_enable_bm25=False")
         hi = lo + len(mine)
         self.lo, self.hi, self.n_total = lo, hi, n
         s1.documents = ShardedList(n, lo, mine, missing=None)
@@ -177,9 +251,9 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
                 index.local_index.add(emb)
         s1.faiss_index = index
         if s1.config.enable_bm25:
-            s1.bm25_index = BM25Index(gpu_device=s1._bm25_device())
-            s1.bm25_index.fit(all_documents)
-            s1.bm25_index.documents = []      # (fit keeps a copy of the texts it was given; nothing reads it afterwards)
+            # the lexical index is sharded like everything else: local postings, corpus-wide statistics
+            s1.bm25_index = ShardedBM25(self._dist, self.group, self.world_size, self.rank, lo, gpu_device=s1._bm25_device())
+            s1.bm25_index.fit(mine)
         if self.stage2 is not None and self.stage2.config.precompute_document_embeddings and mine:
             self.stage2.index_documents(mine, lo)          # token matrices of MY rows only
         if self.stage3 is not None and self.config.stage3_cache_document_tokens and mine:
@@ -372,10 +446,90 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
         return info
 
     # -- persistence: one file set per rank ----------------------------------------------------------------
+    def _shard_files(self, index_path: Optional[str]):
+        import os
+        if index_path is None:
+            index_path = os.path.join(self.config.index_dir, "pipeline_index.pkl")
+        base = os.path.splitext(index_path)[0] + f".shard{self.rank}of{self.world_size}"
+        return base + ".json", base + ".matrix.npy", base + ".stage2_tokens.safetensors"
+
     def save_index(self, index_path: Optional[str] = None):
-        raise ValueError("a row-sharded pipeline is rebuilt from its documents (add_documents / add_documents_shard): "
-                         "per-rank persistence is not part of this build")
+        """Every rank writes what IT holds next to `index_path`: `<base>.shard<r>of<R>.json` (rows, documents and
+        metadata of the shard; JSON like the single-process manifest, never a pickle), `.matrix.npy` (its rows of
+        the corpus matrix) and `.stage2_tokens.safetensors` (its token matrices).  The reference's counterpart is
+        RetrievalPipeline.save_index (src/retrieval_pipeline.py:450-470) over one process."""
+        import json
+        import os
+        if not self.stage1 or not self._indexed:
+            raise ValueError("Pipeline not initialized")
+        manifest_path, matrix_path, tokens_path = self._shard_files(index_path)
+        os.makedirs(os.path.dirname(os.path.abspath(manifest_path)), exist_ok=True)
+        s1 = self.stage1
+        local = s1.faiss_index.local_index
+        mat = local.reconstruct_n(0, local.ntotal) if local.ntotal else np.zeros((0, int(s1.faiss_index.d)), np.float32)
+        np.save(matrix_path, np.asarray(mat, dtype=np.float32))
+        have_tokens = bool(self.stage2 is not None and self.stage2.config.precompute_document_embeddings
+                           and self.stage2.save_token_store(tokens_path))
+        manifest = {"format": "tristage-rag_amd/shard/1", "world_size": self.world_size, "rank": self.rank,
+                    "n_total": self.n_total, "rows": [self.lo, self.hi], "dim": int(s1.faiss_index.d),
+                    "documents": list(s1.documents.items), "doc_metadata": list(s1.doc_metadata.items),
+                    "matrix": os.path.basename(matrix_path),
+                    "stage2_tokens": os.path.basename(tokens_path) if have_tokens else None}
+        with open(manifest_path, "w") as f:
+            json.dump(manifest, f)
+        if self.world_size > 1:
+            self._dist.barrier(group=self.group)
+        self.logger.info(f"Pipeline shard {self.rank}/{self.world_size} saved to {manifest_path}")
 
     def load_index(self, index_path: Optional[str] = None):
-        raise ValueError("a row-sharded pipeline is rebuilt from its documents (add_documents / add_documents_shard): "
-                         "per-rank persistence is not part of this build")
+        """Restore what save_index wrote for THIS rank of the SAME world size: the corpus rows go back into the HIP
+        index as they were stored (no re-encoding), the token store comes from its file (re-encoded if the file is
+        missing or was written for another model), the stage-3 token ids and the BM25 postings are recomputed from
+        the shard's text (the BM25 statistics are all-gathered again)."""
+        import json
+        import os
+        if self._indexed:
+            raise ValueError("ShardedRetrievalPipeline takes the corpus in one add_documents / load_index call")
+        if not self.stage1:
+            self.initialize_stages()
+        manifest_path, matrix_path, tokens_path = self._shard_files(index_path)
+        if not os.path.exists(manifest_path):
+            raise ValueError(f"{manifest_path} not found: a sharded index is loaded by the same number of ranks that saved it")
+        manifest = json.load(open(manifest_path))
+        if (manifest.get("format") != "tristage-rag_amd/shard/1" or manifest["world_size"] != self.world_size
+                or manifest["rank"] != self.rank):
+            raise ValueError(f"{manifest_path} was not written by rank {self.rank} of {self.world_size}")
+        s1 = self.stage1
+        n, (lo, hi) = int(manifest["n_total"]), manifest["rows"]
+        if (lo, hi) != tuple(shard_bounds(n, self.world_size, self.rank)):
+            raise ValueError("shard bounds of the file do not match this world size")
+        mine = list(manifest["documents"])
+        self.lo, self.hi, self.n_total = lo, hi, n
+        s1.documents = ShardedList(n, lo, mine, missing=None)
+        s1.doc_metadata = ShardedList(n, lo, list(manifest["doc_metadata"]), missing={})
+        mat = np.load(os.path.join(os.path.dirname(os.path.abspath(manifest_path)), manifest["matrix"]), allow_pickle=False)
+        d = int(manifest["dim"])
+        local = s1._index_factory(d) if s1._index_factory is not None else None
+        index = ShardedFlatIPIndex(d, n, dtype=s1.config.index_dtype, device=s1.config.gpu_index_device,
+                                   group=self.group, local_index=local, merge_fn=getattr(self, "_merge_fn", None))
+        if mat.shape[0]:
+            index.local_index.add(np.ascontiguousarray(mat, dtype=np.float32))   # stored rows are already normalised
+        s1.faiss_index = index
+        if s1.config.enable_bm25:
+            s1.bm25_index = ShardedBM25(self._dist, self.group, self.world_size, self.rank, lo, gpu_device=s1._bm25_device())
+            s1.bm25_index.fit(mine)
+        if self.stage2 is not None and self.stage2.config.precompute_document_embeddings and mine:
+            ok = bool(manifest.get("stage2_tokens")) and self.stage2.load_token_store(tokens_path, len(mine))
+            if not ok:
+                self.stage2.reset_token_store()
+                self.stage2.index_documents(mine, lo)
+        if self.stage3 is not None and self.config.stage3_cache_document_tokens and mine:
+            self.stage3._pairs = None
+            self.stage3.index_documents(mine, lo)
+        if self.world_size > 1:
+            for st in (self.stage2, self.stage3):
+                if st is not None:
+                    st.owner_compact = True
+        self._install_owner_scoring()
+        self._indexed = True
+        self.logger.info(f"Pipeline shard {self.rank}/{self.world_size} loaded from {manifest_path}")

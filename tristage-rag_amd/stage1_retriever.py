@@ -110,7 +110,11 @@ class BM25Index:
         text = re.sub(r"[^a-z0-9\s]", " ", text)
         return text.split()
 
-    def fit(self, documents: Sequence[str]) -> None:
+    def fit(self, documents: Sequence[str], stats_exchange=None) -> None:
+        """``stats_exchange(df, total_len, n_docs) -> (df, total_len, n_docs)`` (optional): the corpus-wide document
+        frequencies, token count and document count when `documents` is only one row shard of the corpus
+        (parallel_pipeline.ShardedBM25 all-gathers them): idf and the average length are then the GLOBAL ones, so a
+        document's score is exactly what an index over the whole corpus gives it; ids stay local."""
         self.documents = list(documents)
         self.corpus_size = len(self.documents)
         keep = self.refit_compat and bool(self.doc_freqs)
@@ -136,10 +140,13 @@ class BM25Index:
                 if i < n:
                     post_d[t].append(i)
                     post_tf[t].append(c)
+        total_len, n_idf = sum(self.doc_lens), n
+        if stats_exchange is not None:
+            df, total_len, n_idf = stats_exchange(dict(df), total_len, n)
         self.vocabulary = set(df)
-        self.avg_doc_len = sum(self.doc_lens) / n if n > 0 else 0
+        self.avg_doc_len = total_len / n_idf if n_idf > 0 else 0
         for t, d_ in df.items():
-            self.idf[t] = math.log((n - d_ + 0.5) / (d_ + 0.5) + 1.0)
+            self.idf[t] = math.log((n_idf - d_ + 0.5) / (d_ + 0.5) + 1.0)
         self._postings = {t: (np.asarray(post_d[t], dtype=np.int64), np.asarray(post_tf[t], dtype=np.float64))
                           for t in post_d}
         lens = np.asarray(self.doc_lens[:n], dtype=np.float64)
