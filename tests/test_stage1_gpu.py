@@ -53,6 +53,41 @@ def test_more_than_64_queries_and_k_larger_than_n():
     idx.close()
 
 
+def test_k_beyond_the_select_kernels_and_big_async_batches_have_a_slow_path():
+    """limits that used to refuse.  k > 16384 on more than 16384 rows (the select kernels hold
+    16384 keys in LDS): every score from the HIP dense scan + one stable device sort — exact, ties by ascending id,
+    FAISS padding beyond ntotal; numpy and tensor queries, an id offset (a shard).  More than 256 queries in one
+    asynchronous call: sliced."""
+    import torch
+    n, d = 40_000, 32
+    base = make_corpus(n // 2, d, seed=4, dtype="f16")
+    corpus = np.concatenate([base, base])                  # every row twice: exact ties far apart in id
+    queries = make_corpus(3, d, seed=6, dtype="f16")
+    idx = _index(d, "f16", corpus)
+    for k in (20_000, 45_000):
+        D, I = idx.search(queries, k)
+        D0, I0 = oracle.ip_topk(corpus, queries, k)
+        kk = min(k, n)
+        assert (I[:, kk:] == -1).all() and (I0[:, kk:] == -1).all()
+        check_topk(D[:, :kk], I[:, :kk], corpus, queries, kk)
+        for q in range(3):                                 # duplicated rows: the smaller id first
+            pos = {int(i): r for r, i in enumerate(I[q, :kk])}
+            twins = [(i, i + n // 2) for i in range(0, n // 2, 997) if i in pos and i + n // 2 in pos]
+            assert twins and all(pos[a] < pos[b] for a, b in twins)
+    idx.set_id_offset(1000)
+    Dt, It = idx.search(torch.from_numpy(queries).cuda().half(), 20_000)
+    assert int(It.min()) == 1000 and int(It.max()) == 1000 + n - 1
+    idx.set_id_offset(0)
+    # 300 queries in ONE asynchronous call
+    big = make_corpus(300, d, seed=8, dtype="f16")
+    want_D, want_I = idx.search(big, 50)
+    qb = torch.from_numpy(big).cuda().half()
+    Da, Ia = idx.search(qb, 50, async_=True)
+    assert idx.finish() == []
+    assert np.array_equal(Ia.cpu().numpy(), want_I) and np.array_equal(Da.cpu().numpy(), want_D)
+    idx.close()
+
+
 def test_exact_ties_are_ordered_by_ascending_id():
     rng = np.random.default_rng(3)
     base = make_corpus(64, 128, seed=9, dtype="f16")

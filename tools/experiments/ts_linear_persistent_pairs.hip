@@ -93,7 +93,7 @@ __device__ __forceinline__ float fs_gelu(float u) { return (u * 0.5f) * (1.0f + 
 //
 // Round 2 launched one workgroup per tile of 32*QH activation rows; a wave took weight blocks w, w + 8, ... and issued,
 // per k step, one 1 KiB weight load and QH x (ds_read_b128 of the activation fragment, MFMA).  What bounded it
-// (M = 172 032, Q/K/V shape 384 -> 1152; tools/r03_linear*.sh, tools/trace_linear.py):
+// (M = 172 032, Q/K/V shape 384 -> 1152; tools/sessions/r03_linear*.sh, tools/trace_linear.py):
 //   * 0.258 ms whatever the rows per workgroup (64 ... 192), two 4-waves-per-SIMD workgroups per CU or one persistent
 //     2-waves-per-SIMD workgroup, with a 5.8 us or a 1.5 us epilogue: ~70 cycles per MFMA per SIMD instead of 32.  One
 //     ds_read_b128 per MFMA is 1 KiB of LDS traffic per 32 matrix-pipe cycles and SIMD: four SIMDs ask for 128 B/clk,

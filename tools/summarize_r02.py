@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 output of tools/r02_final_a.sh into the small files kept under profiles/."""
+"""Condense the rocprofv3 output of tools/sessions/r02_final_a.sh into the small files kept under profiles/."""
 import collections, csv, glob, json, os, sys
 src = sys.argv[1]
 OURS = ("scan_kernel", "fused_kernel", "select_kernel", "tau_kernel", "qprep", "relayout", "head_start", "maxsim")

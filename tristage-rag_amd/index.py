@@ -58,6 +58,8 @@ class FlatIPIndex:
 
     supports_out = True  # search(..., out=(D, I)) writes into caller tensors
     PENDING_PASSES = 240  # passes of <= 32 queries that may wait for finish() (the library tracks 256)
+    MAX_KERNEL_K = 16384  # the select kernels hold 16384 keys in LDS; larger k: _search_large_k
+    MAX_ASYNC_QUERIES = 128  # per asynchronous library call (4 passes of >= 32 queries)
 
     def __init__(self, d: int, dtype: str = "f32", device: int = 0):
         if dtype not in _NAME_TO_DTYPE:
@@ -106,6 +108,7 @@ class FlatIPIndex:
 
     def set_id_offset(self, offset: int) -> None:
         _lib.check(self._lib.ts_index_set_id_offset(self._h, int(offset)))
+        self._id_offset = int(offset)
 
     def add(self, x, normalize: bool = False) -> None:
         """Append rows ``x`` [n, d] (numpy float32/float16 or a CUDA tensor)."""
@@ -149,6 +152,19 @@ class FlatIPIndex:
         k = int(k)
         if k <= 0:
             raise ValueError("k must be positive")
+        if k > self.MAX_KERNEL_K and self.ntotal > self.MAX_KERNEL_K:
+            return self._search_large_k(q, k, out)
+        if async_ and _is_tensor(q) and q.is_cuda and q.shape[0] > self.MAX_ASYNC_QUERIES:
+            # the library takes at most 4 passes (256 queries) per asynchronous call: larger batches go in slices
+            torch = _torch()
+            B = q.shape[0]
+            D, I = out if out is not None else (torch.empty((B, k), dtype=torch.float32, device=q.device),
+                                                torch.empty((B, k), dtype=torch.int64, device=q.device))
+            for s in range(0, B, self.MAX_ASYNC_QUERIES):
+                e = min(B, s + self.MAX_ASYNC_QUERIES)
+                self.search(q[s:e], k, exact_dense=exact_dense, async_=True, out=(D[s:e], I[s:e]),
+                            inputs_ready=inputs_ready, classic=classic, one_launch=one_launch)
+            return D, I
         flags = _lib.TS_FLAG_NO_FILTER if exact_dense else 0
         if classic or self.classic_filter:   # the five-launch filter path even where the one-launch scan is the default (A/B, tests)
             flags |= _lib.TS_FLAG_CLASSIC
@@ -199,6 +215,43 @@ class FlatIPIndex:
         self._search_raw(q.ctypes.data, B, _NP_DTYPES[q.dtype], k, D.ctypes.data, I.ctypes.data,
                          flags | _lib.TS_FLAG_HOST_PTR, 0)
         return D, I
+
+    def _search_large_k(self, q, k: int, out=None):
+        """k > 16384 on a corpus of more than 16384 rows (the select kernels keep 16384 keys in LDS; FAISS itself takes
+        any k on the CPU, reference src/stage1_retriever.py:380): every inner product from the HIP dense scan
+        (ts_index_scores), then ONE stable descending device sort per slice of queries — equal scores keep ascending
+        row order, the canonical tie rule — and the FAISS padding (-1 / -FLT_MAX) beyond ntotal.  Exact; not a fast path:
+        it materialises 4 B x queries x rows."""
+        torch = _torch()
+        was_np = not (_is_tensor(q) and q.is_cuda)
+        dev = torch.device("cuda", self.device)
+        qt = torch.as_tensor(np.ascontiguousarray(q.detach().cpu().numpy() if _is_tensor(q) else q, dtype=np.float32)).to(dev) if was_np else q
+        if qt.dim() != 2 or qt.shape[1] != self.d:
+            raise ValueError(f"expected [B, {self.d}] queries, got {tuple(qt.shape)}")
+        n, B = self.ntotal, qt.shape[0]
+        if n == 0:
+            raise ValueError("No documents indexed. Call add_documents() first.")
+        kk = min(k, n)
+        if out is not None and not was_np:
+            D, I = out
+        else:
+            D = torch.empty((B, k), dtype=torch.float32, device=dev)
+            I = torch.empty((B, k), dtype=torch.int64, device=dev)
+        D[:, kk:] = -3.4028234663852886e38
+        I[:, kk:] = -1
+        step = max(1, int(2e9 // (4 * max(n, 1))))          # <= 2 GB of scores per slice
+        off = int(self._id_offset_value())
+        for s in range(0, B, step):
+            sc = self.scores(qt[s: s + step])
+            srt, idx = torch.sort(sc, dim=1, descending=True, stable=True)
+            D[s: s + step, :kk] = srt[:, :kk]
+            I[s: s + step, :kk] = idx[:, :kk] + off
+        if was_np:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    def _id_offset_value(self) -> int:
+        return getattr(self, "_id_offset", 0)
 
     def scores(self, q):
         """All inner products, in row order: float32 [B, ntotal] (a CUDA tensor for tensor

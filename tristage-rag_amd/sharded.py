@@ -111,7 +111,7 @@ class ShardedFlatIPIndex:
         # on 8 ranks, never searches locally, never ran out of room, and met the others' all_reduce with its next
         # all_gather: a hang after ~30 batches.)  PENDING_PASSES passes of <= 32 queries is the local index's own limit,
         # which it can only reach later than this count does.  A finish() drains the pipeline (0.7 ms at 2.5 M rows per
-        # rank, tools/r03_outlier.sh): every 120 batches, not every 30 as in round 2.
+        # rank, tools/sessions/r03_outlier.sh): every 120 batches, not every 30 as in round 2.
         passes = (B + 31) // 32
         limit = int(getattr(self.local_index, "PENDING_PASSES", 60))
         if async_ and self._pending_passes and (len(self._pending) >= 120 or self._pending_passes + passes > limit):
