@@ -549,10 +549,11 @@ def main():
             enc_leg = encode_leg(args, torch, index, device, tdt, max(4, min(args.steps, 20)), world)
         except Exception as e:  # the secondary leg must never take the headline measurement down
             enc_leg = {"error": repr(e)}
-        try:    # the same with the query forward replayed from a HIP graph (PipelineConfig.use_hip_graphs)
-            enc_leg.update(encode_leg(args, torch, index, device, tdt, max(4, min(args.steps, 20)), world, graphs=True))
-        except Exception as e:
-            enc_leg["hip_graph_error"] = repr(e)
+        if world == 1:   # (graph capture beside a live RCCL communicator is not something this leg should risk)
+            try:    # the same with the query forward replayed from a HIP graph (PipelineConfig.use_hip_graphs)
+                enc_leg.update(encode_leg(args, torch, index, device, tdt, max(4, min(args.steps, 20)), world, graphs=True))
+            except Exception as e:
+                enc_leg["hip_graph_error"] = repr(e)
 
     if world == 1 and not args.no_pipeline_leg:
         try:
