@@ -1076,15 +1076,35 @@ __global__ __launch_bounds__(512) void read_probe_kernel(const probe_u32x4* corp
   const int lane = threadIdx.x & 63;
   const int64_t W = (int64_t)gridDim.x * (blockDim.x >> 6);
   probe_u32x4 acc = {0u, 0u, 0u, 0u};
-  for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < nblk; b += W) {
-    const probe_u32x4* q = corpus + (size_t)b * kg * 64 + lane;
-    for (int g = 0; g < kg; g += 8) {     // (kg is a multiple of TS_RING = 8: ts_make_layout)
-      probe_u32x4 v[8];
+  // two groups of 8 loads alternate, so 8-16 KiB per wave are always in flight (the scan keeps 8 KiB in its ring and a
+  // few waits apart; a probe that waited for each group before requesting the next read SLOWER than the scan).  No
+  // branch around a load: the group index is clamped instead (a wave re-reads at most its last two groups).
+  const int64_t b0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int gpb = kg / 8;                                       // groups of 8 units per row block
+  const int64_t myblocks = b0 < nblk ? (nblk - b0 + W - 1) / W : 0;
+  const int64_t ng = myblocks * gpb;
+  if (ng == 0) return;
+  auto group = [&](int64_t t) -> const probe_u32x4* {
+    t = t < ng ? t : ng - 1;
+    return corpus + ((size_t)(b0 + (t / gpb) * W) * kg + (size_t)(t % gpb) * 8) * 64 + lane;
+  };
+  probe_u32x4 va[8], vb[8];
+  {
+    const probe_u32x4* q = group(0);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(q + (size_t)(g + i) * 64);
+    for (int i = 0; i < 8; ++i) va[i] = __builtin_nontemporal_load(q + (size_t)i * 64);
+  }
+  for (int64_t t = 0; t < ng; t += 2) {
+    const probe_u32x4* qb = group(t + 1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc ^= v[i];
-    }
+    for (int i = 0; i < 8; ++i) vb[i] = __builtin_nontemporal_load(qb + (size_t)i * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc ^= va[i];
+    const probe_u32x4* qa = group(t + 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) va[i] = __builtin_nontemporal_load(qa + (size_t)i * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc ^= vb[i];
   }
   if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9e3779b9u) sink[0] = 1u;   // keeps the loads alive; practically never true
 }
