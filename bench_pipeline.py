@@ -6,6 +6,11 @@ weights exist offline), i.e. throughput and stage shares only — not a quality 
 bench.py (stage-1 at 10M x 768) stays the headline measurement.
 
     python bench_pipeline.py [--docs 3633] [--queries 16] [--cache]
+    python bench_pipeline.py --gpus N --store --ids --many 64 [--docs D]    # row-sharded over N ranks (starts them itself)
+
+With --gpus N > 1 the pipeline is parallel_pipeline.ShardedRetrievalPipeline: corpus rows, stage-2 token store,
+stage-3 token ids, BM25 postings and text row-sharded over N ranks (RCCL; TS_BENCH_BACKEND=gloo rehearses the same
+code path with ranks sharing GPUs), every rank issues the same search_many calls, the time is the maximum over ranks.
 """
 import argparse
 import json
@@ -38,6 +43,7 @@ def parse_args(argv=None):
     ap.add_argument("--tune-gemms", action="store_true", help="PyTorch TunableOp for the GEMMs (stage-3 widths padded to multiples of 16; "
                     "one untimed pass over the queries first, so that every shape is tuned before the timed region)")
     ap.add_argument("--keep", action="store_true", help="save_intermediate_results (all three record lists are built)")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks of a row-sharded pipeline (one process per GPU)")
     ap.add_argument("--many", type=int, default=0,
                     help="queries per RetrievalPipeline.search_many call (every stage batched); 0 = search() per query")
     return ap.parse_args(argv)
@@ -49,6 +55,21 @@ def run(args):
     import numpy as np
     import torch
     from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("TS_BENCH_BACKEND", "nccl")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     rng = np.random.default_rng(0)
     vocab = [f"w{i}" for i in range(5000)]
@@ -64,7 +85,12 @@ def run(args):
                         stage3_cache_document_tokens=args.ids, save_intermediate_results=args.keep,
                         stage3_many_batch_size=args.s3_batch, tune_gemms=args.tune_gemms,
                         stage3_width_multiple=16 if args.tune_gemms else 1)
-    p = RetrievalPipeline(config=pc)
+    if world > 1:
+        from tristage_rag_amd.parallel_pipeline import ShardedRetrievalPipeline
+        pc.log_file = f"/tmp/ts_pipeline_rank{rank}.log"
+        p = ShardedRetrievalPipeline(config=pc)
+    else:
+        p = RetrievalPipeline(config=pc)
     p.initialize_stages()
     if args.no_lean and hasattr(p.stage3.model, "lean_forward"):
         p.stage3.model.lean_forward = False
@@ -98,6 +124,9 @@ def run(args):
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     if args.many:
         outs = []
@@ -106,7 +135,13 @@ def run(args):
     else:
         outs = [p.search(q) for q in queries]
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     if prof is not None:
         import pstats
         prof.disable()
@@ -118,9 +153,15 @@ def run(args):
     graph_state = {"stage1": None if g1 is None else {"buckets": sorted(g1._graphs), "eager_fallback": g1._broken},
                    "stage2": None if g2 is None else {"buckets": sorted(g2._graphs), "eager_fallback": g2._broken},
                    "stage3": None if g3 is None else {"buckets": sorted(g3._graphs), "eager_fallback": g3._broken}}
+    shard = p.shard_info() if world > 1 else None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return {
         "metric": "full 3-stage pipeline queries/sec (random-init models, throughput only)",
-        "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": 1,
+        "value": round(len(queries) / dt, 3), "unit": "queries/s", "n_gpus": world,
+        "backend": ("rccl" if backend == "nccl" else backend + " (REHEARSAL: ranks may share GPUs)") if world > 1 else "none",
+        "rank0_shard": shard,
         "config": {"workload": f"{args.docs} synthetic docs, S1 top-1000 -> S2 keep 100 -> S3 top-10, bf16",
                    "stage1": args.stage1, "stage2": args.stage2, "stage3": args.stage3,
                    "stage2_token_cache": args.cache, "stage2_token_store": args.store, "hip_graphs": args.graphs,
@@ -137,8 +178,22 @@ def run(args):
 
 
 def main():
-    print(json.dumps(run(parse_args())))
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # become the launcher (nothing here has touched HIP yet)
+        import bench
+        backend = os.environ.get("TS_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and bench.visible_gpus() < args.gpus:
+            sys.stderr.write(f"bench_pipeline.py: --gpus {args.gpus} but fewer GPUs are visible\n")
+            return 2
+        return bench.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        sys.stderr.write("bench_pipeline.py: --gpus does not match WORLD_SIZE\n")
+        return 2
+    out = run(args)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -90,3 +90,22 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["backend"] == "gloo"
     assert out["distinct_devices"] == 1 and "REHEARSAL" in out["config"]["workload"]
     assert out["value"] > 0 and out["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_bench_pipeline_gpus_2_runs_the_row_sharded_pipeline():
+    """`python bench_pipeline.py --gpus 2 --store --ids --many 8` starts its own two ranks (gloo rehearsal: both on the
+    one GPU of the test box) and times ShardedRetrievalPipeline.search_many: one JSON line from rank 0, n_gpus 2,
+    rank 0 holding half of the rows / token matrices."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TS_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_pipeline.py"), "--gpus", "2", "--docs", "600", "--queries", "16",
+                        "--store", "--ids", "--many", "8", "--stage1", "random:tiny", "--stage2", "random:tiny",
+                        "--stage3", "random:tiny"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["array_path"]
+    assert out["rank0_shard"]["rows"] == [0, 300] and out["rank0_shard"]["documents_total"] == 600
+    assert out["rank0_shard"]["stage2_token_rows"] > 0 and out["rank0_shard"]["stage3_id_cache_documents"] == 300

@@ -326,3 +326,64 @@ def test_collective_finish_cadence_is_the_same_on_ranks_with_empty_shards(tmp_pa
     sizes = [int(np.load(tmp_path / f"empty{r}.npy")[0]) for r in range(world)]
     assert 0 in sizes and max(sizes) > 0                       # at least one empty and one non-empty shard
     assert calls[0] == calls[1] == calls[2] and len(calls[0]) >= 3   # two forced finishes + the final one
+
+
+def _tiny_pipeline_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import datetime
+    from doubles import (OracleIndex, oracle_maxsim, oracle_maxsim_indexed, oracle_maxsim_indexed_batch, oracle_merge)
+    from tristage_rag_amd.encoders import SentenceEncoder
+    from tristage_rag_amd.parallel_pipeline import ShardedRetrievalPipeline
+    from tristage_rag_amd.retrieval_pipeline import PipelineConfig, RetrievalPipeline
+    from tristage_rag_amd.stage1_retriever import Stage1Config, Stage1Retriever
+    from tristage_rag_amd.stage2_rescorer import ColBERTScorer, Stage2Config
+    from tristage_rag_amd.stage3_reranker import AdaptiveCrossEncoderReranker, Stage3Config
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        docs = ["alpha beta gamma d0", "neural network retrieval d1", "gpu memory token index d2", "query vector alpha d3"]
+
+        def build(cls):
+            pc = PipelineConfig(stage1_model="random:tiny", stage2_model="random:tiny", stage3_model="random:tiny",
+                                device="cpu", cache_dir=os.path.join(out_dir, "m"), index_dir=os.path.join(out_dir, "i"),
+                                log_file=os.path.join(out_dir, f"t{rank}.log"), log_level="ERROR", stage1_top_k=4,
+                                stage2_top_k=3, stage3_top_k=2, save_intermediate_results=True,
+                                stage2_precompute_document_embeddings=True, stage3_cache_document_tokens=True)
+            p = cls(config=pc)
+            p.stage1 = Stage1Retriever(Stage1Config(model_name="random:tiny", device="cpu", cache_dir=pc.cache_dir,
+                                                    index_dir=pc.index_dir, top_k_candidates=4),
+                                       model=SentenceEncoder("random:tiny", device="cpu"),
+                                       index_factory=lambda d: OracleIndex(d))
+            p.stage2 = ColBERTScorer(Stage2Config(model_name="random:tiny", device="cpu", top_k_candidates=3,
+                                                  precompute_document_embeddings=True),
+                                     maxsim_fn=oracle_maxsim, maxsim_indexed_fn=oracle_maxsim_indexed,
+                                     maxsim_indexed_batch_fn=oracle_maxsim_indexed_batch)
+            p.stage3 = AdaptiveCrossEncoderReranker(Stage3Config(model_name="random:tiny", device="cpu", top_k_final=2))
+            return p
+        par, single = build(ShardedRetrievalPipeline), build(RetrievalPipeline)
+        par._merge_fn = oracle_merge
+        par.add_documents(docs)                       # 4 documents on 3 ranks: rows 0-1, 2-3 and NOTHING on rank 2
+        single.add_documents(docs)
+        assert par.hi - par.lo == (2, 2, 0)[rank] and par._arrays_agreed()
+        qs = ["neural network", "alpha d3", "gpu"]
+        for got, want in zip(par.search_many(qs) + [par.search(qs[1])], single.search_many(qs) + [single.search(qs[1])]):
+            for stage, key in (("stage1_results", "stage1_score"), ("stage2_results", "stage2_score"), ("results", "stage3_score")):
+                assert [r["doc_id"] for r in got[stage]] == [r["doc_id"] for r in want[stage]], stage
+                np.testing.assert_allclose([r[key] for r in got[stage]], [r[key] for r in want[stage]], atol=2e-5)
+                assert all(r["document"] == docs[r["doc_id"]] for r in got[stage])
+        json.dump({"ok": True}, open(os.path.join(out_dir, f"tiny{rank}.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_stage_pipeline_with_an_empty_shard(tmp_path):
+    """Fewer documents than the ranks can share evenly (4 on 3 ranks: the ceil division leaves rank 2 with nothing): the
+    rank without rows, token store, id cache or BM25 postings takes part in every collective (all-gathers, the two
+    all-reduce(MAX), the text gather, the BM25 statistics exchange) and every rank returns the single-process records."""
+    world = 3
+    mp.spawn(_tiny_pipeline_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"tiny{r}.json") for r in range(world))

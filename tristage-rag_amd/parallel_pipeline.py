@@ -221,12 +221,20 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
                              f"{hi - lo} documents, got {len(my_documents)}")
         self._add(list(my_documents), metadata, int(n_total), lo)
 
+    def _place_on_this_ranks_gpu(self) -> None:
+        """One process per GPU: the HIP index and the BM25 postings of this rank live on the process's CURRENT device
+        (the launcher's LOCAL_RANK via torch.cuda.set_device), not on Stage1Config's default device 0."""
+        s1 = self.stage1
+        if torch.cuda.is_available() and s1._device_path():
+            s1.config.gpu_index_device = int(torch.cuda.current_device())
+
     def _add(self, mine: List[str], my_meta, n: int, lo: int) -> None:
         if self._indexed:
             raise ValueError("ShardedRetrievalPipeline takes the corpus in one add_documents call")
         if not self.stage1:
             self.initialize_stages()
         s1 = self.stage1
+        self._place_on_this_ranks_gpu()
         hi = lo + len(mine)
         self.lo, self.hi, self.n_total = lo, hi, n
         s1.documents = ShardedList(n, lo, mine, missing=None)
@@ -500,6 +508,7 @@ class ShardedRetrievalPipeline(RetrievalPipeline):
                 or manifest["rank"] != self.rank):
             raise ValueError(f"{manifest_path} was not written by rank {self.rank} of {self.world_size}")
         s1 = self.stage1
+        self._place_on_this_ranks_gpu()
         n, (lo, hi) = int(manifest["n_total"]), manifest["rows"]
         if (lo, hi) != tuple(shard_bounds(n, self.world_size, self.rank)):
             raise ValueError("shard bounds of the file do not match this world size")
