@@ -238,17 +238,30 @@ def encode_leg(args, torch, index, device, tdt, steps, world):
     if args.dim % 64:
         return None
     spec = args.encoder or f"random:bert:{args.dim}:12:{args.dim // 64}"
-    # (eager written-out forward: replaying the 64-query forward from a HIP graph measured 17.5 k vs 18.8 k queries/s
-    # here — at 64 x 16 tokens the forward is no longer launch-bound and the graph's staging copies cost more)
+    # (the eager written-out forward.  Replaying the 64-query forward from a HIP graph was measured twice this round:
+    # 17.5 k queries/s on the search's stream, 18.5 k on a second stream, against 18.8 k / 20.2 k eager — the forward's
+    # 1.3 ms of GPU time does not hide under a scan that occupies 7/8 of the CUs)
     enc = SentenceEncoder(spec, device=str(device))
     rng = np.random.default_rng(99)
     vocab = [f"w{i}" for i in range(5000)]
     texts = [[" ".join(rng.choice(vocab, size=int(rng.integers(4, 16)))) for _ in range(args.batch)] for _ in range(4)]
 
+    # The query forward of batch i+1 runs on its OWN stream beside the scan of batch i (the scan leaves an eighth of the
+    # CUs free and is HBM-bound; the forward is ~180 small kernels): on one stream the GPU ran them one after the other,
+    # 3.39 ms per step of which 2.2 ms are the scan.  The search waits for the batch's query tensor through an event.
+    main = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device=device)
+
     def one(i, async_):
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            e = enc.encode(texts[i % 4], batch_size=args.batch, convert_to_numpy=False, convert_to_tensor=True)
-        q = (e / (e.norm(dim=1, keepdim=True) + 1e-8)).to(tdt)
+        side.wait_stream(main) if not async_ else None
+        with torch.cuda.stream(side):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                e = enc.encode(texts[i % 4], batch_size=args.batch, convert_to_numpy=False, convert_to_tensor=True)
+            q = (e / (e.norm(dim=1, keepdim=True) + 1e-8)).to(tdt)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        main.wait_event(ready)
+        q.record_stream(main)
         return index.search(q, args.k, async_=True) if async_ else index.search(q, args.k)
 
     for i in range(2):
@@ -272,7 +285,7 @@ def encode_leg(args, torch, index, device, tdt, steps, world):
     enc_ms = (time.perf_counter() - te) / 4 * 1e3
     return {"encode_plus_stage1_qps": round(args.batch * steps / dt, 2), "steps": steps,
             "ms_per_step": round(dt / steps * 1e3, 4), "encode_ms_per_batch": round(enc_ms, 4),
-            "encoder": spec + " (random init, hash tokenizer, bf16 autocast)"}
+            "encoder": spec + " (random init, hash tokenizer, bf16 autocast; forward of batch i+1 on a second stream beside the scan of batch i)"}
 
 
 def pipeline_legs(torch):
