@@ -279,7 +279,7 @@ class CrossEncoderReranker:
                 raw[sel] = self.model.activate(self.model.logits_from_ids(enc)).reshape(-1)
                 continue
             enc = pa.batch(plan, sel, width=int(widths[j]))
-            lg = self.model.logits_graphed(enc) if graph_one or (P <= bs and P == whole) else None   # one query's pairs: graph replay if enabled
+            lg = self.model.logits_graphed(enc) if (P <= bs and P == whole) else None   # one query's pairs, all of them here: graph replay if enabled
             raw[sel] = self.model.activate(lg if lg is not None else self.model.logits_from_ids(enc)).reshape(-1)
         if idx is None:
             return torch.where(owned, raw, raw_full).view(B, C)
