@@ -119,6 +119,12 @@ def spawn_ranks(n, cmd, env=None, relay=sys.stdout, log=sys.stderr, timeout=None
 
     def pump(src, dst, tag):
         for line in iter(src.readline, ""):
+            # rank 0's stdout carries THE json line; anything else a library prints there (gloo's "[Gloo] Rank 0 is
+            # connected ..." for one) goes to the log, so that the caller's stdout is exactly one line
+            if not tag and dst is relay and not line.lstrip().startswith("{"):
+                log.write("[rank 0] " + line)
+                log.flush()
+                continue
             dst.write(tag + line if tag else line)
             dst.flush()
         src.close()

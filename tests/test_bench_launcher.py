@@ -32,14 +32,16 @@ def test_launcher_module_imports_without_torch():
 def test_ranks_see_the_torchrun_environment():
     b = _bench_module()
     out, log = io.StringIO(), io.StringIO()
-    child = ("import os, json; print(json.dumps({k: os.environ.get(k) for k in "
+    child = ("import os, json; print('[lib] chatter on stdout'); print(json.dumps({k: os.environ.get(k) for k in "
              "('RANK','LOCAL_RANK','WORLD_SIZE','LOCAL_WORLD_SIZE','MASTER_ADDR','MASTER_PORT','HSA_ENABLE_IPC_MODE_LEGACY')}))")
     rc = b.spawn_ranks(3, [sys.executable, "-c", child], relay=out, log=log)
     assert rc == 0
-    mine = json.loads(out.getvalue())                       # rank 0's stdout only
+    assert out.getvalue().count("\n") == 1 and "[rank 0] [lib] chatter" in log.getvalue()   # exactly one line reaches the caller
+    mine = json.loads(out.getvalue())                       # rank 0's json line only
     assert mine["RANK"] == "0" and mine["LOCAL_RANK"] == "0" and mine["WORLD_SIZE"] == "3"
     assert mine["MASTER_ADDR"] == "127.0.0.1" and int(mine["MASTER_PORT"]) > 0 and mine["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    others = [json.loads(l.split("] ", 1)[1]) for l in log.getvalue().splitlines() if l.startswith("[rank ")]
+    others = [json.loads(l.split("] ", 1)[1]) for l in log.getvalue().splitlines()
+              if l.startswith("[rank ") and not l.startswith("[rank 0]") and "{" in l]
     assert sorted(o["RANK"] for o in others) == ["1", "2"]
     assert all(o["MASTER_PORT"] == mine["MASTER_PORT"] and o["WORLD_SIZE"] == "3" for o in others)
 
