@@ -88,6 +88,7 @@ struct Ms16Params {
   uint32_t* best;          // [n_docs][lq_pad] ordered-uint keys of max_j cos(q_i, d_j); 0 = none
   int mode;
   float* out;
+  int eq_slices;           // single-query launches: equal tile counts on fewer waves (see "this wave's slice")
 };
 
 // Wave-uniform table reads inside the streaming loop must be SCALAR loads: as vector loads
@@ -353,8 +354,24 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   // ---- this wave's slice of the tile sequence (wave-major numbering spreads the longer
   // slices over all workgroups)
   const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
-  const int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
-  const int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
+  int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
+  int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
+  if (p.eq_slices) {
+    // ONE query: T / n_waves is a small number (4.3 at 1000 candidates on 1024 waves), so a third of the waves own one
+    // tile more than the rest and stream it alone at the rate ONE ring sustains while the chip idles (slices done at
+    // 32-44 us, tools/trace_maxsim.py).  The stream itself is HBM-bound, not wave-bound — so use FEWER waves, each with
+    // the same t = ceil(T / n_waves) tiles: ceil(T / t) waves on the first workgroups (880 of 1024 at 5 tiles each),
+    // the others leave.  Only while >= 3/4 of the waves stay (below that the launch is latency-bound anyway).
+    const int64_t t = (T + n_waves - 1) / n_waves;
+    const int64_t w_eff = t > 0 ? (T + t - 1) / t : 0;
+    if (t > 0 && t <= 10 && 4 * w_eff >= 3 * n_waves) {   // (A/B at 600 ... 4000 candidates, tools/sessions/r03_maxsim_ab.sh: -3 % at 1000, +-1 % at 600 / 1500 / 2000, +1.5 % at 4000)
+      const int64_t wg_eff = (w_eff + M16_WAVES - 1) / M16_WAVES;
+      if ((int64_t)blockIdx.x >= wg_eff) return;     // (uniform for the workgroup; nothing staged, no barrier pending)
+      gw = (int64_t)wave * wg_eff + blockIdx.x;
+      lo = gw < w_eff ? gw * t : T;
+      hi = lo + t < T ? lo + t : T;
+    }
+  }
   const bool has_work = lo < hi;   // (a wave without tiles still stages its share of the query image)
 
   int doc = 0, tile = 0, len = 1;
@@ -678,6 +695,10 @@ int ts_launch_maxsim16(const void* q, int Lq, const void* docs, const int32_t* d
   Ms16Params p;
   p.q = (const unsigned char*)q; p.Lq = Lq; p.H = row_bytes; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
   p.docs = (const unsigned char*)docs; p.mode = mode; p.nq = 0;
+  p.eq_slices = 1;
+#ifdef TS_TUNING
+  if (getenv("TS_M16_NO_EQ")) p.eq_slices = 0;
+#endif
   const int chunk_max = M16_MAX_DOCS;
   const size_t cells = (size_t)std::min(n_docs, chunk_max) * (1 + (size_t)lq_pad);
   std::lock_guard<std::mutex> lk(g_mu);
@@ -754,6 +775,10 @@ int ts_launch_maxsim16_batch(const void* q, const int32_t* q_off, int nq, const 
   p.H = row_bytes; p.s_pad = s_pad; p.lq_pad = lq_pad; p.passes = passes;
   p.docs = (const unsigned char*)store; p.doc_off = nullptr; p.mode = mode;
   p.Lq = max_lq; p.n_docs = max_cand;
+  p.eq_slices = (nq == 1 && grid == g_cus[device]) ? 1 : 0;   // ONE query in the batch form (RetrievalPipeline.search)
+#ifdef TS_TUNING
+  if (getenv("TS_M16_NO_EQ")) p.eq_slices = 0;
+#endif
   const bool full = (row_bytes % (32 * M16_RING)) == 0;
   std::lock_guard<std::mutex> lk(g_mu);
   for (int j0 = 0; j0 < nq; j0 += M16_MAX_BATCH) {   // (one launch unless > 64 queries)
