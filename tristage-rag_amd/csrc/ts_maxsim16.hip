@@ -61,6 +61,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define M16_NEG (-3.402823466e38f)
 
+__device__ const u32x4 m16_zero16 = {0u, 0u, 0u, 0u};   // what the query image's padding lanes load
+
 #define M16_MAX_DOCS 4096   // candidates per launch (their tile prefix sums live in LDS)
 #define M16_MAX_BATCH 64    // queries per launch
 
@@ -277,7 +279,11 @@ extern "C" int ts_debug_m16_trace(unsigned long long* out) {
   } while (0)
 #endif
 
-template <int DT, int NQT, bool FULL>
+// SINGLE: the launch scores ONE query (its prologue is on the critical path: the query image comes by LDS-DMA before
+// the ring's first loads, the slices are equal); otherwise many queries share the launch, a workgroup's prologue runs
+// beside its neighbours' streaming, and the ring's loads go out first (measured both ways: the single-query order costs
+// the 64-query launch 3-4 %, the batch order costs the single query ~2 us).
+template <int DT, int NQT, bool FULL, bool SINGLE>
 __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   Ms16Params p = pin;
   if (pin.nq) {  // one of several queries: narrow every array to this query's part
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   const int64_t n_waves = (int64_t)gridDim.x * M16_WAVES;
   int64_t gw = (int64_t)wave * gridDim.x + blockIdx.x;
   int64_t lo = gw * T / n_waves, hi = (gw + 1) * T / n_waves;
-  if (p.eq_slices) {
+  if (SINGLE && p.eq_slices) {
     // ONE query: T / n_waves is a small number (4.3 at 1000 candidates on 1024 waves), so a third of the waves own one
     // tile more than the rest and stream it alone at the rate ONE ring sustains while the chip idles (slices done at
     // 32-44 us, tools/trace_maxsim.py).  The stream itself is HBM-bound, not wave-bound — so use FEWER waves, each with
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
     const int64_t w_eff = t > 0 ? (T + t - 1) / t : 0;
     if (t > 0 && t <= 10 && 4 * w_eff >= 3 * n_waves) {   // (A/B at 600 ... 4000 candidates, tools/sessions/r03_maxsim_ab.sh: -3 % at 1000, +-1 % at 600 / 1500 / 2000, +1.5 % at 4000)
       const int64_t wg_eff = (w_eff + M16_WAVES - 1) / M16_WAVES;
-      if ((int64_t)blockIdx.x >= wg_eff) return;     // (uniform for the workgroup; nothing staged, no barrier pending)
+      if ((int64_t)blockIdx.x >= wg_eff) return;     // (uniform for the workgroup; BEFORE the image's LDS-DMA is requested: nothing in flight, no barrier pending)
       gw = (int64_t)wave * wg_eff + blockIdx.x;
       lo = gw < w_eff ? gw * t : T;
       hi = lo + t < T ? lo + t : T;
@@ -374,25 +380,83 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
   }
   const bool has_work = lo < hi;   // (a wave without tiles still stages its share of the query image)
 
+  // ---- Q image: unit (g*NQT + t)*64 + l = the 16 bytes at byte 32g + 16(l>>5) of query row q0 + 32t + (l&31), by
+  // LDS-DMA (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform LDS base + lane * 16 — a
+  // wave's 64 lanes fill 64 consecutive units), requested HERE, before the slice search and long before the ring:
+  // no registers are parked, the L2 round trips run under the binary search, and the image is not queued behind the
+  // first 16 MB of ring loads.  (Round 2 requested it after the ring — complete at 8.3 us, every wave idle on a full
+  // ring for ~2 us; through registers before the ring it cost the ring 3 us; parked in registers across the search it
+  // made the compiler re-order the ring's refills.  tools/trace_maxsim.py.)  Lanes outside the image's valid part
+  // (query tokens >= Lq, bytes >= H) read 16 zero bytes.
+  if constexpr (SINGLE) {
+    const int units = S * NQT * 64;
+    for (int u0 = wave * 64; u0 < units; u0 += M16_THREADS) {     // (uniform per wave: units is a multiple of 64)
+      const int u = u0 + lane;
+      const int l = u & 63, t = (u >> 6) % NQT, g = (u >> 6) / NQT;
+      const int qi = q0 + 32 * t + (l & 31), k = 32 * g + 16 * (l >> 5);   // k: byte offset in the row
+      const bool ok = qi < p.Lq && k < H;
+      const unsigned char* src = ok ? p.q + (size_t)qi * H + k : reinterpret_cast<const unsigned char*>(&m16_zero16);
+      // (inline asm, not __builtin_amdgcn_global_load_lds: the compiler's waitcnt pass books the builtin as a pending
+      // "flat" access that only a vmcnt(0) it can see clears, and until then turns EVERY vector-memory wait into
+      // vmcnt(0) — with the partial wait below that is the tile loop's vmcnt(15..9) ladder, i.e. the ring drained once
+      // per tile.  Unknown to the compiler the requests are harmless: they are older than every load it counts and
+      // vmcnt retires in order, so its waits can only come out stricter, never too lenient.)
+      const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(qlds + u0);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is "reserved": it is the instruction's LDS base, and is named so the compiler knows it changed)
+      __asm__ volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off"
+                       :: "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(src) : "m0", "memory");
+#pragma clang diagnostic pop
+    }
+  }
+
+
   int doc = 0, tile = 0, len = 1;
   int64_t start = 0;
   if (has_work) {
-    int a = 0, b = p.n_docs;  // prefix[a] <= lo < prefix[b]
+    // the last candidate a with prefix[a] <= lo (invariant prefix[a] <= lo < prefix[b]), 64 probes per LDS round trip:
+    // two round trips up to 4096 candidates where a bisection takes twelve dependent ones (~1 us of the prologue)
+    int a = 0, b = p.n_docs;
     while (b - a > 1) {
-      const int m = (a + b) >> 1;
-      if ((int64_t)prefix[m] <= lo) a = m; else b = m;
+      const int step = (b - a + 63) >> 6;
+      const int m = a + lane * step;
+      const bool le = m < b && (int64_t)prefix[min(m, b)] <= lo;   // (true on a prefix of the lanes: prefix[] is non-decreasing; lane 0 by the invariant)
+      const int cnt = __builtin_popcountll(__ballot(le));
+      a = a + (cnt - 1) * step;
+      b = min(a + step, b);
     }
     doc = __builtin_amdgcn_readfirstlane(a);
     tile = __builtin_amdgcn_readfirstlane((int)(lo - prefix[a]));
     len = m16_len_s(p, doc);
     start = m16_start_s(p, doc);
   }
-  // (Round 3: the image is staged BEFORE the ring's first loads go out.  Round 2 requested it after them: loads
-  // return in order, so it sat behind 1024 waves x 16 KiB of first ring loads and was complete only at 8.3 us — ring
-  // issued at 4.4 us, first tile done at 16.4 us, every wave idling on a full ring for ~2 us; tools/trace_maxsim.py.)
-  // ---- Q image: unit (g*NQT + t)*64 + l = the 16 bytes at byte 32g + 16(l>>5) of query row q0 + 32t + (l&31)
-  // (8 independent L2 reads in flight per thread: one at a time costs ~1 us each)
-  {
+  const unsigned char* cur = p.docs;
+  u32x4 ring[M16_RING];
+  if (has_work) {
+    const int rows = min(32, len - tile * 32);
+    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
+#pragma unroll
+    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
+  }
+  M16_STAMP(2);
+  if constexpr (SINGLE) {
+    // the query image requested above (LDS-DMA) has to be complete, for every wave of the workgroup, before the first
+    // tile is multiplied.  Its requests are OLDER than the ring's M16_RING loads and vmcnt retires in order, so
+    // vmcnt(M16_RING) is exactly "the image has landed" and the ring stays in flight across the barrier.
+    static_assert(M16_RING == 16, "the wait below is vmcnt(16)");
+    if (has_work) __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16): [3:0] = 0, [15:14] = 1; expcnt/lgkmcnt untouched
+    else __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): no ring behind the image
+    // A bare s_barrier: __syncthreads() (and a workgroup fence, even an LDS-only one) put vmcnt(0) in front of the
+    // barrier = the ring drained.  What the barrier orders here is only the image's LDS-DMA writes (complete: the
+    // vmcnt wait above, in every wave) against the ds_reads below; the asm clobbers keep the compiler from moving
+    // LDS accesses across it.
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __asm__ volatile("" ::: "memory");
+  }
+  if constexpr (!SINGLE) {
+    // ---- Q image through registers, AFTER the ring's first loads (a launch of many queries: other workgroups stream
+    // meanwhile): 8 independent L2 reads in flight per thread (one at a time costs ~1 us each)
     const int units = S * NQT * 64;
     for (int u0 = tid; u0 < units; u0 += 8 * M16_THREADS) {
       u32x4 v[8];
@@ -412,23 +476,13 @@ __global__ __launch_bounds__(M16_THREADS) void maxsim16_kernel(Ms16Params pin) {
         if (u < units) qlds[u] = v[j];
       }
     }
+    // Explicit vmcnt(0): the stores above sit under a lane predicate, so on their skip path the compiler's scoreboard
+    // still counts the staging loads as pending and would put a vmcnt(0) in front of the first reuse of their
+    // registers — inside the tile loop, where it drains the ring once per tile.  (The ring's first loads are older
+    // than the staging loads and are needed next anyway.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+    __syncthreads();
   }
-  // Explicit vmcnt(0): the stores above sit under a lane predicate, so on their skip path the
-  // compiler's scoreboard still counts the staging loads as pending and would put a
-  // vmcnt(0) in front of the first reuse of their registers — inside the tile loop, where it
-  // drains the ring once per tile.  (The ring's first loads are older than the staging loads and
-  // are needed next anyway.)
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-  __syncthreads();
-  const unsigned char* cur = p.docs;
-  u32x4 ring[M16_RING];
-  if (has_work) {
-    const int rows = min(32, len - tile * 32);
-    cur = p.docs + ((size_t)(start + tile * 32 + min(r, rows - 1)) * H + 16 * h);
-#pragma unroll
-    for (int i = 0; i < M16_RING; ++i) ring[i] = m16_load<FULL>(cur, i, h, H);
-  }
-  M16_STAMP(2);
 
   if (!has_work) return;  // (no block-level barrier below)
 
@@ -652,14 +706,18 @@ extern "C" int ts_maxsim_release_scratch(int32_t device) {
   return TS_OK;
 }
 
-template <int DT, int NQT, bool FULL>
-static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s, int nq = 1) {
-  auto kern = maxsim16_kernel<DT, NQT, FULL>;
+template <int DT, int NQT, bool FULL, bool SINGLE>
+static int launch_main_s(const Ms16Params& p, int grid, size_t lds, hipStream_t s, int nq) {
+  auto kern = maxsim16_kernel<DT, NQT, FULL, SINGLE>;
   static TsDeviceOnce lds_attr;  // per instantiation, per device (ts_common.h)
   TS_CHECK(ts_allow_max_lds(lds_attr, reinterpret_cast<const void*>(kern)));
   hipLaunchKernelGGL(kern, dim3(grid, p.passes, nq), dim3(M16_THREADS), lds, s, p);
   TS_HIP(hipGetLastError());
   return TS_OK;
+}
+template <int DT, int NQT, bool FULL>
+static int launch_main(const Ms16Params& p, int grid, size_t lds, hipStream_t s, int nq = 1) {
+  return nq <= 1 ? launch_main_s<DT, NQT, FULL, true>(p, grid, lds, s, nq) : launch_main_s<DT, NQT, FULL, false>(p, grid, lds, s, nq);
 }
 
 // returns TS_ERR_UNSUPPORTED (without setting an error) when the shape is not one this
