@@ -44,9 +44,9 @@ extern "C" {
 /* Bumped whenever an existing signature or the meaning of an argument changes, or entry points are added
  * (a caller built against version N may load any library whose ts_abi_version() == N; nothing older, nothing
  * newer).  1 = round 1 (24 entry points).  2 = round 2 changed ts_attention_varlen (offsets, window, rotary
- * tables) and added 15 entry points; round 3 added ts_index_read_probe and the stage-2 / stage-3 additions
- * listed at their declarations.                                                                            */
-#define TS_ABI_VERSION 2
+ * tables) and added 15 entry points.  3 = round 3 added ts_index_read_probe, ts_index_filter_path and
+ * ts_linear_add_layernorm.                                                                                  */
+#define TS_ABI_VERSION 3
 
 typedef struct ts_index ts_index; /* opaque */
 
@@ -348,6 +348,19 @@ int ts_linear_tile_weight(const void* w, int32_t dtype, int32_t N, int32_t K, vo
                           int32_t device, void* stream);
 int ts_linear_act(const void* w_tiled, const void* x, const void* bias, int32_t dtype, int64_t M,
                   int32_t N, int32_t K, int32_t act, void* out, int32_t device, void* stream);
+
+/* BertSelfOutput / BertOutput of a post-LN encoder in ONE kernel (the cross-encoder the reference reaches through
+ * CrossEncoder.predict, /root/reference/src/stage3_reranker.py:127-131; transformers' modeling_bert
+ * BertSelfOutput.forward / BertOutput.forward: dense -> dropout -> LayerNorm(hidden + input)):
+ *     y = LayerNorm(round_dtype(x[M, K] w[N, K]^T + bias[N]) + residual[M, N]) * gamma + beta
+ * w_tiled from ts_linear_tile_weight; x, bias (may be NULL) of dtype (TS_F16 / TS_BF16); residual fp32 (may be
+ * NULL), gamma fp32 [N], beta fp32 [N] or NULL; y is written as fp32 (out_f32, the next residual) and / or in
+ * dtype (out_lp, the next GEMM's input) — at least one of them.  The roundings are those of ts_linear_act
+ * followed by ts_add_layernorm, and so are the bits.  N a multiple of 32 up to 384 (a workgroup owns whole
+ * rows: the projection's output never goes to HBM), K a multiple of 384; pointers 16-byte aligned (bias 8).   */
+int ts_linear_add_layernorm(const void* w_tiled, const void* x, const void* bias, const float* residual,
+                            const float* gamma, const float* beta, float eps, int32_t dtype, int64_t M,
+                            int32_t N, int32_t K, float* out_f32, void* out_lp, int32_t device, void* stream);
 
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */

@@ -696,3 +696,51 @@ def test_tiled_linear_matches_torch(dt):
         TiledLinear(torch.zeros((384, 1536), dtype=tdt, device="cuda"))       # K too long: the library GEMM's case
     with pytest.raises(ValueError):
         lin(x.float())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_tiled_linear_add_layernorm_equals_the_two_kernels(dt):
+    """TiledLinear.add_layernorm (ts_linear_add_layernorm: BertSelfOutput / BertOutput as one kernel — the rows' reduction
+    in 384-wide chunks through a double-buffered LDS image, the projection's output staged in LDS, LayerNorm rows by the
+    same routine as ts_add_layernorm) against ts_linear_act followed by ts_add_layernorm: the SAME bits (fp32 stream and
+    16-bit copy), and against torch in fp32 within the 16-bit rounding of the projection.  Ragged row counts (the last
+    workgroup's tile is partial), one and four chunks, N below 384, no residual / no beta / no fp32 output."""
+    import torch
+    import torch.nn.functional as F
+    from tristage_rag_amd.index import TiledLinear, add_layernorm
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    step = 2.0 ** (-8 if dt == "bf16" else -11)
+    g = torch.Generator(device="cuda").manual_seed(47)
+    for M, K, N in ((5000, 384, 384), (4097, 1536, 384), (1, 384, 384), (95, 768, 256), (97, 384, 32), (20000, 1536, 384)):
+        x = (torch.randn((M, K), generator=g, device="cuda") * 0.8).to(tdt)
+        w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(tdt)
+        b = (torch.randn((N,), generator=g, device="cuda") * 0.1).to(tdt)
+        res = torch.randn((M, N), generator=g, device="cuda")
+        gamma = 1.0 + 0.1 * torch.randn((N,), generator=g, device="cuda")
+        beta = 0.1 * torch.randn((N,), generator=g, device="cuda")
+        lin = TiledLinear(w, b, with_layernorm=True)
+        for r, bt in ((res, beta), (None, beta), (res, None)):
+            y32, ylp = lin.add_layernorm(x, r, gamma, bt, 1e-12)
+            assert y32.shape == (M, N) and y32.dtype == torch.float32 and ylp.dtype == tdt
+            # the two-kernel path on the same tiled weight (ts_linear_act takes any K that is a multiple of 128)
+            o = lin(x)
+            e32, elp = add_layernorm(o, r, gamma, bt, 1e-12, lp_dtype=tdt)
+            if N > 32:
+                assert torch.equal(y32, e32), (M, K, N, float((y32 - e32).abs().max()))
+                assert torch.equal(ylp, elp)
+            else:   # (ts_add_layernorm keeps ONE chunk per lane at N <= 128 and the compiler contracts that instance differently: 2e-7)
+                assert float((y32 - e32).abs().max()) <= 1e-6
+            # torch, fp32 end to end: the projection's output is rounded to 16 bits once on our side
+            ref = F.layer_norm(F.linear(x.float(), w.float(), b.float()) + (r if r is not None else 0.0), (N,), gamma, bt, 1e-12)
+            assert float((y32 - ref).abs().max()) <= 12 * step * max(1.0, float(ref.abs().max()))
+        only_lp = lin.add_layernorm(x, res, gamma, beta, 1e-12, want_f32=False)
+        assert only_lp[0] is None and torch.equal(only_lp[1], lin.add_layernorm(x, res, gamma, beta, 1e-12)[1])
+        x3 = x.view(1, M, K)
+        assert lin.add_layernorm(x3, res.view(1, M, N), gamma, beta, 1e-12)[0].shape == (1, M, N)
+    assert TiledLinear.usable_with_layernorm(384, 1536) and not TiledLinear.usable_with_layernorm(768, 768)
+    assert not TiledLinear.usable_with_layernorm(384, 512)
+    with pytest.raises(ValueError):
+        TiledLinear(torch.zeros((768, 768), dtype=tdt, device="cuda"), with_layernorm=True)
+    with pytest.raises(ValueError):
+        lin.add_layernorm(x, res.to(tdt), gamma, beta, 1e-12)                  # the residual stream is fp32

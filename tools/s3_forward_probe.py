@@ -16,9 +16,10 @@ mask = (t < lens[:, None]).to(torch.int64)
 ids = torch.randint(5, 30000, (B, L), generator=g, device="cuda") * mask
 enc = {"input_ids": ids, "attention_mask": mask, "token_type_ids": torch.zeros_like(ids), "lengths": lens}
 out = {"B": B, "L": L, "valid_tokens": int(lens.sum())}
-for name, attn, ln in (("hip_attention+hip_layernorm", True, True), ("torch_attention+hip_layernorm", False, True), ("torch_both", False, False)):
+for name, attn, ln, fo in (("hip_attention+hip_layernorm", True, True, True), ("the same, projection and LayerNorm as two kernels", True, True, False),
+                           ("torch_attention+hip_layernorm", False, True, False), ("torch_both", False, False, False)):
     lean = ce._lean_model()
-    lean.fused_attention, lean.fused_layernorm = attn, ln
+    lean.fused_attention, lean.fused_layernorm, lean.fused_output_layernorm = attn, ln, fo
     for _ in range(3):
         ce.logits_from_ids(enc)
     torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave phase timeline of ONE ts_linear_act launch (needs a -DTS_TUNING -DFS_TRACE build in TRISTAGE_LIB).
-Stamps: 0 entry, 1 ring issued, 2 x image written to LDS, 3 after the barrier, 5 first unit's k loop done,
-4 first unit done (epilogue included), 7 second unit's piece staged and the next requested, 6 exit."""
+Stamps, compute waves: 0 entry, 1 image share written, 2 past the barrier, 3 block 1 multiplied, 4 block 1 in its slot,
+5 block 2 multiplied, 6 block 2 in its slot, 7 exit; storer waves: 3 / 4 = first / second pair of blocks read out of the slots."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,19 +23,20 @@ lib = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * (4096 * 8))()
 assert lib.ts_debug_fs_trace(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
-t = t[t[:, 6] > 0]
-t0 = t[:, 0].min()
-names = ["entry", "ring issued", "x image in LDS", "after barrier", "unit 1 done", "unit 1 k loop done", "exit", "unit 2 piece staged + requested"]
-order = [0, 1, 2, 3, 5, 4, 7, 6]
-print(f"N={N} K={K} act={act}: {t.shape[0]} waves traced (the first 512 workgroups)")
-rel = (t - t[:, :1]) / 100.0          # us since the wave's own entry
-for i in order:
-    n = names[i]
-    c = rel[:, i]
-    if (t[:, i] <= 0).any():
-        c = c[t[:, i] > 0]
-        if not len(c):
+wave = np.arange(4096) % 12
+t0 = t[t[:, 0] > 0][:, 0].min()
+names = ["entry", "image share written", "past the barrier", "block 1 multiplied | pair 1 read", "block 1 in its slot | pair 2 read",
+         "block 2 multiplied", "block 2 in its slot", "exit"]
+print(f"N={N} K={K} act={act} (the first 341 workgroups)")
+for role, sel in (("compute waves", (wave < 8) & (t[:, 7] > 0)), ("storer waves", (wave >= 8) & (t[:, 7] > 0))):
+    tt = t[sel]
+    rel = (tt - tt[:, :1]) / 100.0
+    print(f" {role}: {tt.shape[0]} traced")
+    for i, n in enumerate(names):
+        ok = tt[:, i] > 0
+        if not ok.any():
             continue
-    print(f"  {i} {n:18s} since entry: min {c.min():7.2f}  median {np.median(c):7.2f}  p95 {np.percentile(c, 95):7.2f}  max {c.max():7.2f} us")
-ent = (t[:, 0] - t0) / 100.0
-print(f"  entry times of the traced waves: median {np.median(ent):.1f} us, max {ent.max():.1f} us; last exit {((t[:, 6] - t0) / 100.0).max():.1f} us")
+        c = rel[ok, i]
+        print(f"  {i} {n:36s} since entry: min {c.min():7.2f}  median {np.median(c):7.2f}  p95 {np.percentile(c, 95):7.2f}  max {c.max():7.2f} us")
+ent = (t[t[:, 0] > 0][:, 0] - t0) / 100.0
+print(f"  entry times of the traced waves: median {np.median(ent):.1f} us, max {ent.max():.1f} us; last exit {((t[t[:, 7] > 0][:, 7] - t0) / 100.0).max():.1f} us")

@@ -16,31 +16,8 @@
 #include "ts_common.h"
 #include <initializer_list>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "ts_ln_dev.h"   // ln_load4 / ln_pack2 / ln_row: the row arithmetic, shared with ts_linear.hip
 #define LN_MAX_CHUNKS 8   // 4-element chunks per lane: H <= 2048
-
-template <int XDT> __device__ __forceinline__ f32x4 ln_load4(const void* p, int64_t idx);
-template <> __device__ __forceinline__ f32x4 ln_load4<TS_F32>(const void* p, int64_t idx) {
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
-}
-template <> __device__ __forceinline__ f32x4 ln_load4<TS_BF16>(const void* p, int64_t idx) {
-  const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + idx);
-  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-               __uint_as_float(u.y & 0xffff0000u)};
-}
-template <> __device__ __forceinline__ f32x4 ln_load4<TS_F16>(const void* p, int64_t idx) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  const h4 v = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(p) + idx);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-__device__ __forceinline__ uint32_t ln_pack2(float a, float b, int dt) {
-  if (dt == TS_F16) {
-    const _Float16 x = (_Float16)a, y = (_Float16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-  }
-  const __bf16 x = (__bf16)a, y = (__bf16)b;   // round to nearest even, like tensor.to(torch.bfloat16)
-  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
 
 struct LnParams {
   const void* x;            // [rows, H] of XDT — or, for the embedding variant, the fp32 word table [V, H]
@@ -111,30 +88,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(LnParams p) {
   while (row < p.rows) {
     const int64_t next = row + stride;
     if (next < p.rows) ln_fetch<XDT, NCH, LPR, EMB>(p, next, lir, nx);
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);   // (chunks beyond H are zeros)
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const float mean = sum / (float)H;
-    float sq = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int e = (c * LPR + lir) * 4;
-      if (e < H) {
-        const f32x4 d = v[c] - mean;
-        sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-      }
-    }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float rstd = 1.0f / sqrtf(sq / (float)H + p.eps);
+    f32x4 yv[NCH];
+    ln_row<NCH, LPR>(v, g, bt, H, lir, p.eps, yv);
     const int64_t base = row * H;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int e = (c * LPR + lir) * 4;
       if (e < H) {
-        const f32x4 y = (v[c] - mean) * rstd * g[c] + bt[c];
+        const f32x4 y = yv[c];
         // (the fp32 stream is next read two GEMMs later: it need not displace the 16-bit copy the next GEMM reads at once)
         if (p.out_f32) __builtin_nontemporal_store(p.prenorm ? v[c] : y, reinterpret_cast<f32x4*>(p.out_f32 + base + e));
         if (p.out_lp) {

@@ -870,16 +870,22 @@ class LeanBertEncoder:
         # the streamed-weight kernel (ts_linear_act) when they live on a GPU in a 16-bit type
         self.fused_linear = True
         self.min_linear_rows = 4096   # below this many tokens the forward is launch-bound and the library GEMM is as good
+        # ... and BertSelfOutput / BertOutput (projection + residual + LayerNorm) as ONE kernel when a workgroup can own
+        # whole rows of the output (H <= 384: ts_linear_add_layernorm; the projection's output never goes to HBM)
+        self.fused_output_layernorm = True
         for p in self.layers:
-            p["tqkv"] = p["to"] = p["t1"] = None
+            p["tqkv"] = p["to"] = p["t1"] = p["to_ln"] = p["t2_ln"] = None
             if compute_dtype in (torch.bfloat16, torch.float16) and p["wqkv"].is_cuda:
                 try:
                     from .index import TiledLinear
                     for key, w, b in (("tqkv", "wqkv", "bqkv"), ("to", "wo", "bo"), ("t1", "w1", "b1")):
                         if TiledLinear.usable(int(p[w].shape[0]), int(p[w].shape[1])):
                             p[key] = TiledLinear(p[w], p[b])
+                    for key, w, b in (("to_ln", "wo", "bo"), ("t2_ln", "w2", "b2")):
+                        if TiledLinear.usable_with_layernorm(int(p[w].shape[0]), int(p[w].shape[1])):
+                            p[key] = p["to"] if key == "to_ln" and p["to"] is not None else TiledLinear(p[w], p[b], with_layernorm=True)
                 except Exception:
-                    p["tqkv"] = p["to"] = p["t1"] = None    # (no library: the GEMMs stay with torch)
+                    p["tqkv"] = p["to"] = p["t1"] = p["to_ln"] = p["t2_ln"] = None    # (no library: the GEMMs stay with torch)
     @torch.no_grad()
     def hidden(self, input_ids, attention_mask, token_type_ids=None, lengths=None):
         """-> (last hidden state float32 [B, L, H], its copy in the compute dtype).  ``lengths`` (int32 [B], optional):
@@ -935,10 +941,17 @@ class LeanBertEncoder:
                 qkv = qkv.view(B, L, 3, nh, dh)
                 q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B, heads, L, dh] views
                 a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(B, L, H)
-            o = p["to"](a) if tl and p["to"] is not None and a.is_contiguous() else F.linear(a, p["wo"], p["bo"])
-            x, xb = add_ln(o, x, p["ln1"])
-            f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
-            x, xb = add_ln(f, x, p["ln2"])
+            fo = tl and self.fused_output_layernorm
+            if fo and p["to_ln"] is not None and a.is_contiguous():
+                x, xb = p["to_ln"].add_layernorm(a, x, *p["ln1"])
+            else:
+                o = p["to"](a) if tl and p["to"] is not None and a.is_contiguous() else F.linear(a, p["wo"], p["bo"])
+                x, xb = add_ln(o, x, p["ln1"])
+            if fo and p["t2_ln"] is not None:
+                x, xb = p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
+            else:
+                f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
+                x, xb = add_ln(f, x, p["ln2"])
         return x, xb
 
     def _up(self, p, xb, tl: bool):
@@ -977,10 +990,17 @@ class LeanBertEncoder:
         for p in self.layers:
             qkv = p["tqkv"](xb) if tl and p["tqkv"] is not None else F.linear(xb, p["wqkv"], p["bqkv"])
             a = attention_varlen(qkv, lengths, nh, out=abuf, offs=offsets, max_len=max_len)   # (every row is a valid token)
-            o = p["to"](a) if tl and p["to"] is not None else F.linear(a, p["wo"], p["bo"])
-            x, xb = add_layernorm(o, x, *p["ln1"], lp_dtype=cd)
-            f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
-            x, xb = add_layernorm(f, x, *p["ln2"], lp_dtype=cd)
+            fo = tl and self.fused_output_layernorm
+            if fo and p["to_ln"] is not None:
+                x, xb = p["to_ln"].add_layernorm(a, x, *p["ln1"])
+            else:
+                o = p["to"](a) if tl and p["to"] is not None else F.linear(a, p["wo"], p["bo"])
+                x, xb = add_layernorm(o, x, *p["ln1"], lp_dtype=cd)
+            if fo and p["t2_ln"] is not None:
+                x, xb = p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
+            else:
+                f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
+                x, xb = add_layernorm(f, x, *p["ln2"], lp_dtype=cd)
         return x, xb
 
 

@@ -646,13 +646,21 @@ class TiledLinear:
     def usable(N: int, K: int) -> bool:
         return N % 32 == 0 and K % 128 == 0 and K <= 384
 
-    def __init__(self, weight, bias=None):
+    @staticmethod
+    def usable_with_layernorm(N: int, K: int) -> bool:
+        """Shapes ``add_layernorm`` takes: a workgroup owns whole rows of the output (N <= 384), the reduction is walked
+        in chunks of 384 (the attention-output and feed-forward down projections of MiniLM-class encoders)."""
+        return N % 32 == 0 and N <= 384 and K % 384 == 0
+
+    def __init__(self, weight, bias=None, with_layernorm: bool = False):
         torch = _torch()
         lib = _lib.load()
         w = weight.detach().contiguous()
         self.N, self.K = int(w.shape[0]), int(w.shape[1])
-        if not w.is_cuda or w.dtype not in (torch.float16, torch.bfloat16) or not self.usable(self.N, self.K):
-            raise ValueError("TiledLinear takes a 16-bit CUDA weight [N, K] with N % 32 == 0, K % 128 == 0, K <= 384")
+        ok = self.usable_with_layernorm(self.N, self.K) if with_layernorm else self.usable(self.N, self.K)
+        if not w.is_cuda or w.dtype not in (torch.float16, torch.bfloat16) or not ok:
+            raise ValueError("TiledLinear takes a 16-bit CUDA weight [N, K] with N % 32 == 0, K % 128 == 0, K <= 384 "
+                             "(with_layernorm: N <= 384, K % 384 == 0)")
         self.dtype, self.device = w.dtype, w.device
         self.bias = bias.detach().to(w.dtype).contiguous() if bias is not None else None
         self.tiled = torch.empty_like(w)
@@ -671,3 +679,31 @@ class TiledLinear:
                                              _tensor_dtype(x), x.numel() // self.K, self.N, self.K, 1 if gelu else 0,
                                              ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
         return out
+
+    def add_layernorm(self, x, residual, gamma, beta, eps: float, want_f32: bool = True):
+        """``LayerNorm(linear(x) + residual) * gamma + beta`` in ONE kernel (ts_linear_add_layernorm; BertSelfOutput /
+        BertOutput): x [..., K] of the weight's dtype, residual fp32 [..., N] or None, gamma / beta fp32 [N].  Returns
+        (y fp32 or None, y in the weight's dtype) — bit-identical to ``add_layernorm(self(x), residual, ...)``."""
+        torch = _torch()
+        if not self.usable_with_layernorm(self.N, self.K):
+            raise ValueError("this weight's shape has no fused LayerNorm kernel (TiledLinear.usable_with_layernorm)")
+        if x.dtype != self.dtype or x.shape[-1] != self.K or not x.is_contiguous() or x.device != self.device:
+            raise ValueError("x must be a contiguous [..., K] tensor of the weight's dtype on its device")
+        shape = tuple(x.shape[:-1]) + (self.N,)
+        if residual is not None:
+            residual = residual.contiguous()
+            if residual.dtype != torch.float32 or tuple(residual.shape) != shape or residual.device != x.device:
+                raise ValueError("residual must be float32 [..., N] on x's device")
+        gamma = gamma.detach().contiguous()
+        beta = beta.detach().contiguous() if beta is not None else None
+        for t in (gamma, beta):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != self.N or t.device != x.device):
+                raise ValueError("gamma / beta must be float32 [N] on x's device")
+        out32 = torch.empty(shape, dtype=torch.float32, device=x.device) if want_f32 else None
+        outlp = torch.empty(shape, dtype=x.dtype, device=x.device)
+        dev = x.device.index
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(_lib.load().ts_linear_add_layernorm(ptr(self.tiled), ptr(x), ptr(self.bias), ptr(residual), ptr(gamma), ptr(beta),
+                                                       float(eps), _tensor_dtype(x), x.numel() // self.K, self.N, self.K,
+                                                       ptr(out32), ptr(outlp), dev, ctypes.c_void_p(_stream_ptr(dev))))
+        return out32, outlp
