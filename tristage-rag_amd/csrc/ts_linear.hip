@@ -13,14 +13,19 @@
 //     MFMA A operand — from L2, where its ~1 MB stays;
 //   * the workgroup's 32*QH activation rows are the "queries": their whole K extent sits in LDS as the B-operand image,
 //     built once from the row-major activations (the only HBM read of the kernel);
-//   * each wave takes weight blocks w, w+8, ...: 32 output features x 32*QH rows per block, bias + GELU in the epilogue,
-//     stored as 16-byte pieces (8 consecutive features of one row, after one exchange between the half-waves).
+//   * each of the 8 compute waves takes weight blocks w, w+8, ...: 32 output features x 32*QH rows per block, bias + GELU in
+//     the epilogue; the finished block goes to the wave's LDS slot, and 4 storer waves write the slots out — 128
+//     contiguous bytes of every row, from their own vmcnt queue (loads and stores share vmcnt on gfx9 and retire in order:
+//     a compute wave that stored its block itself had its next weight refills queued behind the stores);
+//   * workgroups are persistent (tile = blockIdx.x, + gridDim.x, ...): the storers fetch the next tile's rows into registers
+//     while this tile is multiplied and write them into the image between the two barriers that end the tile.
 // The rounding points are those of linear followed by gelu: sum + bias rounded to the 16-bit type, GELU in fp32 on that
 // value (erf to 1.5e-7, Abramowitz & Stegun 7.1.26: after the rounding to 8 / 11 mantissa bits a few values per million
 // differ from torch's in the last bit), rounded again.  Without the activation the results were bit-identical to
 // hipBLASLt's on every shape tried.
 // No K loop with barriers, no operand double buffers: the activations are read from HBM once, W traffic from L2 is
-// M / (32 QH) x |W|.
+// M / (32 QH) x |W|.  The second kernel of this file, proj_ln_kernel (ts_linear_add_layernorm), is the same idea for the
+// two projections that are followed by residual add + LayerNorm, with the reduction in chunks.
 #include "ts_scan_dev.h"
 #include "ts_ln_dev.h"
 #include <atomic>
