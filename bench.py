@@ -551,12 +551,13 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes}
         if not args.no_read_probe:
             try:   # the streaming ceiling of THIS box: the scan's access pattern with the arithmetic taken out
-                pr = local.read_probe(reps=5)
+                local.read_probe(reps=3)          # (the probe follows seconds of host work: clocks and DRAM pages warm first)
+                pr = local.read_probe(reps=10)
                 roof["measured_read_peak"] = round(pr["gbps_avg"], 1)
                 roof["measured_read_peak_best"] = round(pr["gbps_best"], 1)
                 roof["frac_of_measured_read_peak"] = round(achieved / pr["gbps_avg"], 4)
                 roof["read_probe"] = ("ts_index_read_probe: read-only kernel over this index's tiled corpus, same grid / "
-                                      "block order / nt loads as the scan, 5 passes, HIP events")
+                                      "block order / nt loads as the scan, 3 warm-up + 10 timed passes, HIP events")
             except Exception as e:
                 roof["measured_read_peak"] = None
                 roof["read_probe_error"] = repr(e)

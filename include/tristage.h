@@ -352,15 +352,19 @@ int ts_linear_act(const void* w_tiled, const void* x, const void* bias, int32_t 
 /* BertSelfOutput / BertOutput of a post-LN encoder in ONE kernel (the cross-encoder the reference reaches through
  * CrossEncoder.predict, /root/reference/src/stage3_reranker.py:127-131; transformers' modeling_bert
  * BertSelfOutput.forward / BertOutput.forward: dense -> dropout -> LayerNorm(hidden + input)):
- *     y = LayerNorm(round_dtype(x[M, K] w[N, K]^T + bias[N]) + residual[M, N]) * gamma + beta
+ *     y = LayerNorm(round_dtype(a(x)[M, K] w[N, K]^T + bias[N]) + residual[M, N]) * gamma + beta
  * w_tiled from ts_linear_tile_weight; x, bias (may be NULL) of dtype (TS_F16 / TS_BF16); residual fp32 (may be
  * NULL), gamma fp32 [N], beta fp32 [N] or NULL; y is written as fp32 (out_f32, the next residual) and / or in
- * dtype (out_lp, the next GEMM's input) — at least one of them.  The roundings are those of ts_linear_act
- * followed by ts_add_layernorm, and so are the bits.  N a multiple of 32 up to 384 (a workgroup owns whole
- * rows: the projection's output never goes to HBM), K a multiple of 384; pointers 16-byte aligned (bias 8).   */
+ * dtype (out_lp, the next GEMM's input) — at least one of them.  act_in 0: a(x) = x; 1: a(x) = round_dtype(
+ * erf GELU(x)) applied as the rows are staged — BertIntermediate's activation folded into BertOutput, x being
+ * the up projection's output BEFORE its activation (ts_linear_act with act 0): the activation costs no pass
+ * of its own and its arithmetic runs beside this kernel's matrix instructions.  The roundings are those of
+ * (gelu,) ts_linear_act, ts_add_layernorm, and so are the bits.  N a multiple of 32 up to 384 (a workgroup owns
+ * whole rows: the projection's output never goes to HBM), K a multiple of 384; pointers 16-byte aligned (bias 8). */
 int ts_linear_add_layernorm(const void* w_tiled, const void* x, const void* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, int32_t dtype, int64_t M,
-                            int32_t N, int32_t K, float* out_f32, void* out_lp, int32_t device, void* stream);
+                            int32_t N, int32_t K, int32_t act_in, float* out_f32, void* out_lp, int32_t device,
+                            void* stream);
 
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */

@@ -738,6 +738,23 @@ def test_tiled_linear_add_layernorm_equals_the_two_kernels(dt):
         assert only_lp[0] is None and torch.equal(only_lp[1], lin.add_layernorm(x, res, gamma, beta, 1e-12)[1])
         x3 = x.view(1, M, K)
         assert lin.add_layernorm(x3, res.view(1, M, N), gamma, beta, 1e-12)[0].shape == (1, M, N)
+    # BertIntermediate's GELU folded into BertOutput: the up projection WITHOUT its activation, the down kernel applies the
+    # erf GELU (and its rounding) while it stages its rows == the up projection with the GELU in its epilogue, bit for bit
+    for M, H in ((5000, 384), (97, 384), (1000, 256)):
+        x0 = (torch.randn((M, H), generator=g, device="cuda") * 0.8).to(tdt)
+        w1 = (torch.randn((1536, H), generator=g, device="cuda") * 0.06).to(tdt)
+        b1 = (torch.randn((1536,), generator=g, device="cuda") * 0.1).to(tdt)
+        w2 = (torch.randn((H, 1536), generator=g, device="cuda") * 0.03).to(tdt)
+        b2 = (torch.randn((H,), generator=g, device="cuda") * 0.1).to(tdt)
+        res = torch.randn((M, H), generator=g, device="cuda")
+        gamma = 1.0 + 0.1 * torch.randn((H,), generator=g, device="cuda")
+        beta = 0.1 * torch.randn((H,), generator=g, device="cuda")
+        up, down = TiledLinear(w1, b1), TiledLinear(w2, b2, with_layernorm=True)
+        a32, alp = down.add_layernorm(up(x0), res, gamma, beta, 1e-12, gelu_input=True)
+        e32, elp = down.add_layernorm(up(x0, gelu=True), res, gamma, beta, 1e-12)
+        assert torch.equal(a32, e32) and torch.equal(alp, elp)
+        ref = F.layer_norm(F.linear(F.gelu(F.linear(x0.float(), w1.float(), b1.float())), w2.float(), b2.float()) + res, (H,), gamma, beta, 1e-12)
+        assert float((a32 - ref).abs().max()) <= 16 * step * max(1.0, float(ref.abs().max()))
     assert TiledLinear.usable_with_layernorm(384, 1536) and not TiledLinear.usable_with_layernorm(768, 768)
     assert not TiledLinear.usable_with_layernorm(384, 512)
     with pytest.raises(ValueError):

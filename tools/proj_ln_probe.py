@@ -51,4 +51,23 @@ for name, K in (("self_output_K384", 384), ("output_K1536", 1536)):
         t1 = TiledLinear(w, b)
         rec["ts_linear_act_then_add_layernorm_ms"] = round(timed(lambda: add_layernorm(t1(x), res, gamma, beta, 1e-12, lp_dtype=torch.bfloat16)), 4)
     out[name] = rec
+# the whole feed-forward block: up (+ GELU) and down + residual + LayerNorm, the GELU in the up projection's epilogue or
+# folded into the down kernel's row staging
+H = N
+w1 = (torch.randn((4 * H, H), generator=g, device=dev) * 0.05).bfloat16()
+b1 = (torch.randn((4 * H,), generator=g, device=dev) * 0.1).bfloat16()
+w2 = (torch.randn((H, 4 * H), generator=g, device=dev) * 0.03).bfloat16()
+b2 = (torch.randn((H,), generator=g, device=dev) * 0.1).bfloat16()
+x0 = torch.randn((M, H), generator=g, device=dev).bfloat16()
+up, down = TiledLinear(w1, b1), TiledLinear(w2, b2, with_layernorm=True)
+a = down.add_layernorm(up(x0), res, gamma, beta, 1e-12, gelu_input=True)
+b = down.add_layernorm(up(x0, gelu=True), res, gamma, beta, 1e-12)
+out["feed_forward_block"] = {
+    "gelu_in_up_epilogue_ms": round(timed(lambda: down.add_layernorm(up(x0, gelu=True), res, gamma, beta, 1e-12)), 4),
+    "gelu_in_down_staging_ms": round(timed(lambda: down.add_layernorm(up(x0), res, gamma, beta, 1e-12, gelu_input=True)), 4),
+    "up_without_activation_ms": round(timed(lambda: up(x0)), 4), "up_with_gelu_ms": round(timed(lambda: up(x0, gelu=True)), 4),
+    "bit_identical": bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))}
+up_out = up(x0)
+out["feed_forward_block"]["down_with_gelu_input_ms"] = round(timed(lambda: down.add_layernorm(up_out, res, gamma, beta, 1e-12, gelu_input=True)), 4)
+out["feed_forward_block"]["down_ms"] = round(timed(lambda: down.add_layernorm(up_out, res, gamma, beta, 1e-12)), 4)
 print(json.dumps(out))

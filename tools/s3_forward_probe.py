@@ -20,6 +20,8 @@ for name, attn, ln, fo in (("hip_attention+hip_layernorm", True, True, True), ("
                            ("torch_attention+hip_layernorm", False, True, False), ("torch_both", False, False, False)):
     lean = ce._lean_model()
     lean.fused_attention, lean.fused_layernorm, lean.fused_output_layernorm = attn, ln, fo
+    if os.environ.get("S3_GELU_IN_UP"):
+        lean.gelu_in_down = False
     for _ in range(3):
         ce.logits_from_ids(enc)
     torch.cuda.synchronize()

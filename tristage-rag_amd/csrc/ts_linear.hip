@@ -450,14 +450,26 @@ struct PlParams {
 // the 64 units of the group, conflict-free, two per-lane constants (g even / odd).  Writers read the rows coalesced
 // (16 lanes = 256 contiguous bytes of a row, 4 rows per instruction): without the swizzle the 16 pieces of a row land
 // 3 KiB / 512 B apart = in the SAME 16-byte bank group and a 64-lane ds_write_b128 takes 16 passes instead of 4.
-#if defined(TS_TUNING) && defined(DBG_X_NT)
+// (the rows of x are read once: non-temporal, so that they do not push the weight out of L2 — 0.33 -> 0.32 ms at K = 1536)
 #define PL_XLOAD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define PL_XLOAD(ptr) (*(ptr))
-#endif
+// erf GELU of the 8 16-bit values of a piece, each rounded back to 16 bits: what torch's gelu makes of the up projection's
+// output — applied by whoever stages the piece (GELU_IN), so the activation never costs a pass of its own
+template <int DT>
+__device__ __forceinline__ u32x4 pl_gelu8(const u32x4& v) {
+  u32x4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float u0 = fs_to_f32<DT>((uint16_t)v[d]), u1 = fs_to_f32<DT>((uint16_t)(v[d] >> 16));
+    const float y0 = (u0 * 0.5f) * (1.0f + fs_erf(u0 * 0.70710678118654752440f));
+    const float y1 = (u1 * 0.5f) * (1.0f + fs_erf(u1 * 0.70710678118654752440f));
+    o[d] = (uint32_t)fs_from_f32<DT>(y0) | ((uint32_t)fs_from_f32<DT>(y1) << 16);
+  }
+  return o;
+}
 __device__ __forceinline__ int pl_unit_in_group(int h, int row31, int c) { return (32 * h + row31) ^ ((c & 3) << 2); }
 
 // Chunk 0: every thread of the workgroup takes part (t of nt; nt a multiple of 16), three pieces of a row per thread.
+template <int DT, bool GELU_IN>
 __device__ __forceinline__ void pl_load_image0(const PlParams& p, u32x4* dst, int64_t m0, int t, int nt) {
   const int cc = t & 15;
   for (int row = t >> 4; row < PL_ROWS; row += nt >> 4) {
@@ -469,7 +481,7 @@ __device__ __forceinline__ void pl_load_image0(const PlParams& p, u32x4* dst, in
 #pragma unroll
     for (int jc = 0; jc < 3; ++jc) {
       const int c = cc + 16 * jc;
-      dst[(size_t)((c >> 1) * PL_QH + (row >> 5)) * 64 + pl_unit_in_group(c & 1, row & 31, c)] = v[jc];
+      dst[(size_t)((c >> 1) * PL_QH + (row >> 5)) * 64 + pl_unit_in_group(c & 1, row & 31, c)] = GELU_IN ? pl_gelu8<DT>(v[jc]) : v[jc];
     }
   }
 }
@@ -489,15 +501,16 @@ __device__ __forceinline__ void pl_request(const PlParams& p, u32x4 (&v)[PL_LD],
     for (int jc = 0; jc < 3; ++jc) v[3 * jr + jc] = PL_XLOAD(reinterpret_cast<const u32x4*>(src + 128 * jc));
   }
 }
+template <int DT, bool GELU_IN>
 __device__ __forceinline__ void pl_write(const u32x4 (&v)[PL_LD], u32x4* dst, int lt) {
   const int cc = lt & 15, rr = lt >> 4;
   u32x4* base = dst + (cc >> 1) * (PL_QH * 64) + pl_unit_in_group(cc & 1, rr, cc);   // (rr < 16: bit 4 of the unit is free for 16 (jr & 1))
 #pragma unroll
   for (int jr = 0; jr < 6; ++jr)
 #pragma unroll
-    for (int jc = 0; jc < 3; ++jc) base[jc * (8 * PL_QH * 64) + (jr >> 1) * 64 + 16 * (jr & 1)] = v[3 * jr + jc];
+    for (int jc = 0; jc < 3; ++jc) base[jc * (8 * PL_QH * 64) + (jr >> 1) * 64 + 16 * (jr & 1)] = GELU_IN ? pl_gelu8<DT>(v[3 * jr + jc]) : v[3 * jr + jc];
 }
-template <int DT>
+template <int DT, bool GELU_IN>
 __global__ __launch_bounds__(1024) void proj_ln_kernel(PlParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4* img = reinterpret_cast<u32x4*>(smem);
@@ -509,7 +522,7 @@ __global__ __launch_bounds__(1024) void proj_ln_kernel(PlParams p) {
   [[maybe_unused]] const int pl_row = (int)(blockIdx.x * 16 + wave);   // (PL_TRACE builds)
   PL_STAMP(0);
   // ---- chunk 0 of the image: every wave helps
-  pl_load_image0(p, img, m0, tid, nwaves * 64);
+  pl_load_image0<DT, GELU_IN>(p, img, m0, tid, nwaves * 64);
   PL_STAMP(1);
   unsigned char* stg = smem;       // the staging tile takes the images' place after the last chunk
   const int j = lane & 31, h = lane >> 5;
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(1024) void proj_ln_kernel(PlParams p) {
     PL_STAMP(2);
     for (int c = 0; c < p.nchunk; ++c) {
       if (c + 1 < p.nchunk) {
-        pl_write(pre, img + (size_t)((c + 1) & 1) * PL_IMG_UNITS, lt);
+        pl_write<DT, GELU_IN>(pre, img + (size_t)((c + 1) & 1) * PL_IMG_UNITS, lt);
         if (c + 2 < p.nchunk) pl_request(p, pre, m0, c + 2, lt);
       }
       if (c == 0) PL_STAMP(3);
@@ -676,9 +689,9 @@ __global__ __launch_bounds__(1024) void proj_ln_kernel(PlParams p) {
   PL_STAMP(7);
 }
 
-template <int DT>
+template <int DT, bool GELU_IN>
 static int pl_launch(const PlParams& p, hipStream_t s) {
-  auto kern = proj_ln_kernel<DT>;
+  auto kern = proj_ln_kernel<DT, GELU_IN>;
   static TsDeviceOnce attr;
   TS_CHECK(ts_allow_max_lds(attr, reinterpret_cast<const void*>(kern)));
   const size_t images = (size_t)(p.nchunk > 1 ? 2 : 1) * PL_IMG_UNITS * 16, staging = (size_t)PL_ROWS * p.stage_stride;
@@ -691,9 +704,10 @@ static int pl_launch(const PlParams& p, hipStream_t s) {
 
 extern "C" int ts_linear_add_layernorm(const void* w_tiled, const void* x, const void* bias, const float* residual,
                                        const float* gamma, const float* beta, float eps, int32_t dtype, int64_t M, int32_t N,
-                                       int32_t K, float* out_f32, void* out_lp, int32_t device, void* stream) {
+                                       int32_t K, int32_t act_in, float* out_f32, void* out_lp, int32_t device, void* stream) {
   if (M == 0) return TS_OK;
-  if (!w_tiled || !x || !gamma || (!out_f32 && !out_lp) || M < 0 || N <= 0 || K <= 0 || (dtype != TS_F16 && dtype != TS_BF16)) {
+  if (!w_tiled || !x || !gamma || (!out_f32 && !out_lp) || M < 0 || N <= 0 || K <= 0 || (dtype != TS_F16 && dtype != TS_BF16) ||
+      (act_in != 0 && act_in != 1)) {
     ts_set_error("bad arguments to linear_add_layernorm");
     return TS_ERR_INVALID;
   }
@@ -714,7 +728,8 @@ extern "C" int ts_linear_add_layernorm(const void* w_tiled, const void* x, const
   p.gamma = gamma; p.beta = beta; p.eps = eps; p.out_f32 = out_f32; p.out_lp = (uint16_t*)out_lp;
   p.M = M; p.N = N; p.K = K; p.kg = K / 16; p.nblk = N / 32; p.nchunk = K / PL_KC; p.stage_stride = 2 * N + 16;
   hipStream_t s = (hipStream_t)stream;
-  const int st = dtype == TS_BF16 ? pl_launch<TS_BF16>(p, s) : pl_launch<TS_F16>(p, s);
+  const int st = dtype == TS_BF16 ? (act_in ? pl_launch<TS_BF16, true>(p, s) : pl_launch<TS_BF16, false>(p, s))
+                                  : (act_in ? pl_launch<TS_F16, true>(p, s) : pl_launch<TS_F16, false>(p, s));
   if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   return st;
 }
@@ -777,15 +792,23 @@ extern "C" int ts_linear_act(const void* w_tiled, const void* x, const void* bia
     static std::atomic<int> cus_of[64];
     if (device >= 0 && device < 64 && cus_of[device].load(std::memory_order_relaxed) > 0) p.cus = cus_of[device].load(std::memory_order_relaxed);
     else {
-      if (hipGetDeviceProperties(&prop, device) != hipSuccess) { ts_set_error("linear_act: hipGetDeviceProperties failed"); return TS_ERR_HIP; }
+      if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        ts_set_error("linear_act: hipGetDeviceProperties failed");
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        return TS_ERR_HIP;
+      }
       p.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       if (device >= 0 && device < 64) cus_of[device].store(p.cus, std::memory_order_relaxed);
     }
   }
   hipStream_t s = (hipStream_t)stream;
-  int st = TS_ERR_INVALID;
-  if (dtype == TS_BF16) st = qh == 3 ? fs_launch<TS_BF16, 3>(p, s) : qh == 2 ? fs_launch<TS_BF16, 2>(p, s) : fs_launch<TS_BF16, 1>(p, s);
-  else st = qh == 3 ? fs_launch<TS_F16, 3>(p, s) : qh == 2 ? fs_launch<TS_F16, 2>(p, s) : fs_launch<TS_F16, 1>(p, s);
+  auto go = [&](const FsParams& q, int rows32) -> int {
+    if (dtype == TS_BF16) return rows32 == 3 ? fs_launch<TS_BF16, 3>(q, s) : rows32 == 2 ? fs_launch<TS_BF16, 2>(q, s) : fs_launch<TS_BF16, 1>(q, s);
+    return rows32 == 3 ? fs_launch<TS_F16, 3>(q, s) : rows32 == 2 ? fs_launch<TS_F16, 2>(q, s) : fs_launch<TS_F16, 1>(q, s);
+  };
+  // (Tried: the last, partial round of the persistent grid as a second launch with 64-row tiles — 6.7 rounds' worth of
+  // tile time instead of 7 on paper, no difference in the stage-3 forward on one box: tools/sessions/r03_split.sh.)
+  const int st = go(p, qh);
   if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   return st;
 }

@@ -873,6 +873,7 @@ class LeanBertEncoder:
         # ... and BertSelfOutput / BertOutput (projection + residual + LayerNorm) as ONE kernel when a workgroup can own
         # whole rows of the output (H <= 384: ts_linear_add_layernorm; the projection's output never goes to HBM)
         self.fused_output_layernorm = True
+        self.gelu_in_down = True          # ... and the erf GELU between the two feed-forward projections inside the second
         for p in self.layers:
             p["tqkv"] = p["to"] = p["t1"] = p["to_ln"] = p["t2_ln"] = None
             if compute_dtype in (torch.bfloat16, torch.float16) and p["wqkv"].is_cuda:
@@ -948,11 +949,20 @@ class LeanBertEncoder:
                 o = p["to"](a) if tl and p["to"] is not None and a.is_contiguous() else F.linear(a, p["wo"], p["bo"])
                 x, xb = add_ln(o, x, p["ln1"])
             if fo and p["t2_ln"] is not None:
-                x, xb = p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
+                x, xb = self._down_ln(p, xb, x, tl)
             else:
                 f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
                 x, xb = add_ln(f, x, p["ln2"])
         return x, xb
+
+    def _down_ln(self, p, xb, x, tl: bool):
+        """BertIntermediate + BertOutput: up projection, activation, down projection, residual add, LayerNorm — two
+        kernels when the activation is the erf GELU: the up projection writes its output BEFORE the activation and the
+        down kernel applies the GELU while it stages its rows (the erf is vector-ALU work: in the up projection's epilogue
+        it is exposed, beside the down projection's matrix instructions it is not).  Same bits either way."""
+        if tl and p["t1"] is not None and self.act is F.gelu and self.gelu_in_down:
+            return p["t2_ln"].add_layernorm(p["t1"](xb), x, *p["ln2"], gelu_input=True)
+        return p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
 
     def _up(self, p, xb, tl: bool):
         """The feed-forward up projection with its activation: one kernel (GELU in the epilogue) when it applies."""
@@ -997,7 +1007,7 @@ class LeanBertEncoder:
                 o = p["to"](a) if tl and p["to"] is not None else F.linear(a, p["wo"], p["bo"])
                 x, xb = add_layernorm(o, x, *p["ln1"], lp_dtype=cd)
             if fo and p["t2_ln"] is not None:
-                x, xb = p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
+                x, xb = self._down_ln(p, xb, x, tl)
             else:
                 f = F.linear(self._up(p, xb, tl), p["w2"], p["b2"])
                 x, xb = add_layernorm(f, x, *p["ln2"], lp_dtype=cd)

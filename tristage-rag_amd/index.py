@@ -680,10 +680,13 @@ class TiledLinear:
                                              ctypes.c_void_p(out.data_ptr()), dev, ctypes.c_void_p(_stream_ptr(dev))))
         return out
 
-    def add_layernorm(self, x, residual, gamma, beta, eps: float, want_f32: bool = True):
+    def add_layernorm(self, x, residual, gamma, beta, eps: float, want_f32: bool = True, gelu_input: bool = False):
         """``LayerNorm(linear(x) + residual) * gamma + beta`` in ONE kernel (ts_linear_add_layernorm; BertSelfOutput /
         BertOutput): x [..., K] of the weight's dtype, residual fp32 [..., N] or None, gamma / beta fp32 [N].  Returns
-        (y fp32 or None, y in the weight's dtype) — bit-identical to ``add_layernorm(self(x), residual, ...)``."""
+        (y fp32 or None, y in the weight's dtype) — bit-identical to ``add_layernorm(self(x), residual, ...)``.
+        ``gelu_input=True``: ``linear(gelu(x))`` — x is the up projection's output BEFORE its activation, the erf GELU (and
+        its rounding to the 16-bit type) is applied while the rows are staged: bit-identical to passing
+        ``F.gelu``-of-x as produced by ``TiledLinear.__call__(..., gelu=True)``."""
         torch = _torch()
         if not self.usable_with_layernorm(self.N, self.K):
             raise ValueError("this weight's shape has no fused LayerNorm kernel (TiledLinear.usable_with_layernorm)")
@@ -705,5 +708,6 @@ class TiledLinear:
         ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
         _lib.check(_lib.load().ts_linear_add_layernorm(ptr(self.tiled), ptr(x), ptr(self.bias), ptr(residual), ptr(gamma), ptr(beta),
                                                        float(eps), _tensor_dtype(x), x.numel() // self.K, self.N, self.K,
-                                                       ptr(out32), ptr(outlp), dev, ctypes.c_void_p(_stream_ptr(dev))))
+                                                       1 if gelu_input else 0, ptr(out32), ptr(outlp), dev,
+                                                       ctypes.c_void_p(_stream_ptr(dev))))
         return out32, outlp
