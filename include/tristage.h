@@ -335,7 +335,7 @@ int ts_geglu(const void* u, int32_t dtype, int64_t rows, int32_t I, void* out, i
  * out[M, N] = act(x[M, K] w[N, K]^T + bias[N]) for the Q/K/V, attention-output and feed-
  * forward "up" projections of MiniLM-class encoders (K <= 384 is where it beats the
  * library GEMM, 1.2-1.5x; at K = 768 hipBLASLt's stream-K kernels win and the Python
- * host keeps them; any K that is a multiple of 128 up to 2560 is accepted), act 0 = none,
+ * host keeps them; any K that is a multiple of 128 up to 2176 is accepted), act 0 = none,
  * 1 = erf GELU (BertIntermediate: no separate activation pass over the M x N result).
  * The weight is re-tiled ONCE with ts_linear_tile_weight (w [N, K] in torch.nn.Linear
  * layout -> out, N*K elements of the same dtype) and then streamed from L2 by every

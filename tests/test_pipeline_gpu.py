@@ -637,6 +637,14 @@ def test_packed_batches_equal_padded_batches():
         a = ce.logits_from_ids(enc)
         b = ce.logits_from_ids(pk)
         assert a.shape == b.shape and float((a - b).abs().max()) < 4e-3
+        # projection + residual + LayerNorm as one kernel, and the GELU folded into the down kernel's row staging, are
+        # re-arrangements of the same arithmetic: the SAME logits as the kernel-per-step forward, bit for bit
+        lean = ce._lean_model()
+        if lean.layers[0]["t2_ln"] is not None and int(pk["input_ids"].shape[0]) >= lean.min_linear_rows:
+            for fo, gd in ((False, False), (True, False)):
+                lean.fused_output_layernorm, lean.gelu_in_down = fo, gd
+                assert torch.equal(ce.logits_from_ids(pk), b) and torch.equal(ce.logits_from_ids(enc), a)
+            lean.fused_output_layernorm, lean.gelu_in_down = True, True
         ce.lean_forward = False
         ref = ce.logits_from_ids(enc)
         assert float((b - ref).abs().max()) < 4e-3
