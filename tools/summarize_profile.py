@@ -16,13 +16,14 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]   # (gpurun merges every session's files into gpurun_out/: the last one)
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 rows = []
 traffic = {}
 for name in ("pmc_fetch", "pmc_write"):
-    files = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(src, name, "*", "*_counter_collection.csv"))
     if not files:
         continue
     agg = collections.defaultdict(list)
