@@ -684,12 +684,16 @@ def test_tiled_linear_matches_torch(dt):
     tdt = torch.bfloat16 if dt == "bf16" else torch.float16
     step = 2.0 ** (-8 if dt == "bf16" else -11)
     g = torch.Generator(device="cuda").manual_seed(31)
-    for M, K, N in ((5000, 384, 1152), (4097, 384, 384), (1, 384, 1536), (777, 256, 1024), (100, 256, 256), (300, 128, 32)):
+    # (the last four: more tiles than compute units — persistent workgroups take several —, an odd number of 32-feature
+    # blocks above 8 (the two compute waves a storer serves own different numbers of blocks), and reduction dimensions whose
+    # next image does not fit the storers' registers (64- and 32-row tiles))
+    for M, K, N in ((5000, 384, 1152), (4097, 384, 384), (1, 384, 1536), (777, 256, 1024), (100, 256, 256), (300, 128, 32),
+                    (60000, 384, 288), (50011, 128, 352), (40000, 768, 64), (20000, 1536, 96)):
         x = (torch.randn((M, K), generator=g, device="cuda") * 0.8).to(tdt)
         w = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(tdt)
         b = (torch.randn((N,), generator=g, device="cuda") * 0.1).to(tdt)
         for bias in (b, None):
-            lin = TiledLinear(w, bias)
+            lin = TiledLinear(w, bias, with_layernorm=not TiledLinear.usable(N, K))   # (K > 384: admitted as the LayerNorm kernel's weight)
             ref = F.linear(x, w, bias)
             got = lin(x)
             assert got.shape == ref.shape and got.dtype == tdt

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(FS_THREADS + 64 * FS_STORERS) void ffn_stream_kerne
     const int s2 = 2 * (wave - FS_WAVES);
     const int piece = lane & 7, r0 = lane >> 3;
     const unsigned char* my = slots + (size_t)(s2 + (piece >> 2)) * ROWS * FS_SLOT_ROW + 16 * (piece & 3);
-    int seen = 0;                                     // rounds of earlier tiles (the counters run on)
+    int seen = 0, seen_b = 0;                         // blocks of earlier tiles from wave 2 s / from wave 2 s + 1 (the counters run on;
+                                                      // the second wave owns one block fewer per tile when N / 32 is odd)
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       const int64_t m0 = tile * ROWS;
       const bool more = tile + gridDim.x < ntiles;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(FS_THREADS + 64 * FS_STORERS) void ffn_stream_kerne
         const int blk_a = s2 + 8 * n;
         const bool two = blk_a + 1 < nblk;
         fs_wait_counter(slot_full + s2, seen + n + 1);
-        if (two) fs_wait_counter(slot_full + s2 + 1, seen + n + 1);
+        if (two) fs_wait_counter(slot_full + s2 + 1, seen_b + n + 1);
         // in FS_PARTS parts of the rows (the next image is parked in this wave's registers as well: 18 + 12 quads do not fit)
         const int rows_here = (int)((p.M - m0 < ROWS ? p.M - m0 : ROWS)) - r0;     // this lane's rows r0 + 8 i exist while 8 i < rows_here
         uint16_t* orow = p.out + (m0 + r0) * p.N + blk_a * 32 + 8 * piece;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(FS_THREADS + 64 * FS_STORERS) void ffn_stream_kerne
           }
           if (half == FS_PARTS - 1) {
             fs_post_counter(slot_free + s2, seen + n + 1, lane);
-            if (two) fs_post_counter(slot_free + s2 + 1, seen + n + 1, lane);
+            if (two) fs_post_counter(slot_free + s2 + 1, seen_b + n + 1, lane);
             if (seen == 0 && n == 0) FS_STAMP(3);
             if (seen == 0 && n == 1) FS_STAMP(4);
           }
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(FS_THREADS + 64 * FS_STORERS) void ffn_stream_kerne
         }
       }
       seen += n;
+      seen_b += (s2 + 1 < nblk) ? (nblk - s2 - 1 + 7) / 8 : 0;
       if (!more) break;
       fs_barrier();                                   // (A) the compute waves are done with this tile's image
       if (prefetch) fs_write_image<QH>(p, pre, qlds, lt);
