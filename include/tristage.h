@@ -45,7 +45,7 @@ extern "C" {
  * (a caller built against version N may load any library whose ts_abi_version() == N; nothing older, nothing
  * newer).  1 = round 1 (24 entry points).  2 = round 2 changed ts_attention_varlen (offsets, window, rotary
  * tables) and added 15 entry points.  3 = round 3 added ts_index_read_probe, ts_index_filter_path and
- * ts_linear_add_layernorm.                                                                                  */
+ * ts_linear_add_layernorm, ts_mlp_add_layernorm.                                                            */
 #define TS_ABI_VERSION 3
 
 typedef struct ts_index ts_index; /* opaque */
@@ -365,6 +365,18 @@ int ts_linear_add_layernorm(const void* w_tiled, const void* x, const void* bias
                             const float* gamma, const float* beta, float eps, int32_t dtype, int64_t M,
                             int32_t N, int32_t K, int32_t act_in, float* out_f32, void* out_lp, int32_t device,
                             void* stream);
+
+/* BertIntermediate + BertOutput — the whole feed-forward block of a post-LN encoder layer — in ONE kernel:
+ *     y = LayerNorm(round(gelu(round(x[M, H] w1[I, H]^T + b1[I])) w2[H, I]^T + b2[H]) + residual[M, H]) * gamma + beta
+ * (erf GELU; round = to dtype).  The M x I intermediate never leaves the CU (as separate kernels it is written to HBM
+ * and read back: 40 % of a layer's traffic).  w1_tiled / w2_tiled from ts_linear_tile_weight; x, b1, b2 (may be
+ * NULL) of dtype (TS_F16 / TS_BF16); residual fp32 (may be NULL), gamma fp32 [H], beta fp32 [H] or NULL; outputs as
+ * for ts_linear_add_layernorm.  The roundings and the accumulation order are those of ts_linear_act (act 1) followed
+ * by ts_linear_add_layernorm: the same bits.  H = 384 (MiniLM-class: a workgroup owns whole rows), I a multiple of
+ * 384; pointers 16-byte aligned (biases 8).                                                                     */
+int ts_mlp_add_layernorm(const void* w1_tiled, const void* b1, const void* w2_tiled, const void* b2, const void* x,
+                         const float* residual, const float* gamma, const float* beta, float eps, int32_t dtype,
+                         int64_t M, int32_t H, int32_t I, float* out_f32, void* out_lp, int32_t device, void* stream);
 
 /* Frees the internal MaxSim scratch buffers kept per (device, stream) (all devices
  * if device < 0).  No MaxSim launch may be pending on that device.               */

@@ -641,10 +641,10 @@ def test_packed_batches_equal_padded_batches():
         # re-arrangements of the same arithmetic: the SAME logits as the kernel-per-step forward, bit for bit
         lean = ce._lean_model()
         if lean.layers[0]["t2_ln"] is not None and int(pk["input_ids"].shape[0]) >= lean.min_linear_rows:
-            for fo, gd in ((False, False), (True, False)):
-                lean.fused_output_layernorm, lean.gelu_in_down = fo, gd
+            for fo, gd, fm in ((False, False, False), (True, False, False), (True, True, False)):   # (b, a: everything on, the one-kernel feed-forward block included)
+                lean.fused_output_layernorm, lean.gelu_in_down, lean.fused_mlp = fo, gd, fm
                 assert torch.equal(ce.logits_from_ids(pk), b) and torch.equal(ce.logits_from_ids(enc), a)
-            lean.fused_output_layernorm, lean.gelu_in_down = True, True
+            lean.fused_output_layernorm, lean.gelu_in_down, lean.fused_mlp = True, True, True
         ce.lean_forward = False
         ref = ce.logits_from_ids(enc)
         assert float((b - ref).abs().max()) < 4e-3
@@ -765,6 +765,23 @@ def test_tiled_linear_add_layernorm_equals_the_two_kernels(dt):
         a32, alp = down.add_layernorm(up(x0), res, gamma, beta, 1e-12, gelu_input=True)
         e32, elp = down.add_layernorm(up(x0, gelu=True), res, gamma, beta, 1e-12)
         assert torch.equal(a32, e32) and torch.equal(alp, elp)
+        # ... and the whole block as ONE kernel (ts_mlp_add_layernorm: the intermediate never leaves the CU), hidden size 384
+        from tristage_rag_amd.index import mlp_add_layernorm, mlp_usable
+        assert mlp_usable(up, down) == (H == 384)
+        if H == 384:
+            for r, bt in ((res, beta), (None, None)):
+                m32, mlp = mlp_add_layernorm(up, down, x0, r, gamma, bt, 1e-12)
+                w32, wlp = down.add_layernorm(up(x0, gelu=True), r, gamma, bt, 1e-12)
+                assert torch.equal(m32, w32) and torch.equal(mlp, wlp)
+            nb_up, nb_down = TiledLinear(w1, None), TiledLinear(w2, None, with_layernorm=True)       # no biases
+            assert torch.equal(mlp_add_layernorm(nb_up, nb_down, x0, res, gamma, beta, 1e-12)[0],
+                               nb_down.add_layernorm(nb_up(x0, gelu=True), res, gamma, beta, 1e-12)[0])
+            half_up, half_down = TiledLinear(w1[:768].contiguous(), b1[:768].contiguous()), TiledLinear(w2[:, :768].contiguous(), b2, with_layernorm=True)
+            assert torch.equal(mlp_add_layernorm(half_up, half_down, x0, res, gamma, beta, 1e-12, want_f32=False)[1],    # I = 768: two chunks
+                               half_down.add_layernorm(half_up(x0, gelu=True), res, gamma, beta, 1e-12)[1])
+        else:
+            with pytest.raises(ValueError):
+                mlp_add_layernorm(up, down, x0, res, gamma, beta, 1e-12)
         ref = F.layer_norm(F.linear(F.gelu(F.linear(x0.float(), w1.float(), b1.float())), w2.float(), b2.float()) + res, (H,), gamma, beta, 1e-12)
         assert float((a32 - ref).abs().max()) <= 16 * step * max(1.0, float(ref.abs().max()))
     assert TiledLinear.usable_with_layernorm(384, 1536) and not TiledLinear.usable_with_layernorm(768, 768)

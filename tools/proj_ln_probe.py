@@ -67,6 +67,10 @@ out["feed_forward_block"] = {
     "gelu_in_down_staging_ms": round(timed(lambda: down.add_layernorm(up(x0), res, gamma, beta, 1e-12, gelu_input=True)), 4),
     "up_without_activation_ms": round(timed(lambda: up(x0)), 4), "up_with_gelu_ms": round(timed(lambda: up(x0, gelu=True)), 4),
     "bit_identical": bool(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))}
+from tristage_rag_amd.index import mlp_add_layernorm
+c = mlp_add_layernorm(up, down, x0, res, gamma, beta, 1e-12)
+out["feed_forward_block"]["one_kernel_ms"] = round(timed(lambda: mlp_add_layernorm(up, down, x0, res, gamma, beta, 1e-12)), 4)
+out["feed_forward_block"]["one_kernel_bit_identical"] = bool(torch.equal(c[0], b[0]) and torch.equal(c[1], b[1]))
 up_out = up(x0)
 out["feed_forward_block"]["down_with_gelu_input_ms"] = round(timed(lambda: down.add_layernorm(up_out, res, gamma, beta, 1e-12, gelu_input=True)), 4)
 out["feed_forward_block"]["down_ms"] = round(timed(lambda: down.add_layernorm(up_out, res, gamma, beta, 1e-12)), 4)

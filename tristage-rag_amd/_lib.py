@@ -89,6 +89,8 @@ SIGNATURES = {
                                 c_void_p]),
     "ts_linear_add_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int64,
                                           c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "ts_mlp_add_layernorm": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32,
+                                       c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "ts_maxsim_release_scratch": (c_int32, [c_int32]),
     "ts_selftest_device_once": (c_int32, [c_int32, c_int32]),
     "ts_last_error": (c_char_p, []),

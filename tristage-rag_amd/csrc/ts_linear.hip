@@ -28,6 +28,7 @@
 // two projections that are followed by residual add + LayerNorm, with the reduction in chunks.
 #include "ts_scan_dev.h"
 #include "ts_ln_dev.h"
+#include "ts_linear_dev.h"
 #include <atomic>
 
 #if defined(TS_TUNING) && defined(DBG_ONE_B)   // ablation builds only (wrong results): ONE B operand per k group from LDS, used for every row tile
@@ -37,26 +38,6 @@
 #endif
 #define FS_THREADS 512   // 8 waves: each takes weight blocks w, w + 8, ...
 #define FS_WAVES 8
-
-__device__ __forceinline__ float fs_erf(float x) {   // Abramowitz & Stegun 7.1.26, |error| < 1.5e-7
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * ax * ax);
-  return copysignf(fmaf(-poly, e, 1.0f), x);
-}
-template <int DT> __device__ __forceinline__ float fs_to_f32(uint16_t v) {
-  if constexpr (DT == TS_F16) return (float)__builtin_bit_cast(_Float16, v);
-  else return __uint_as_float((uint32_t)v << 16);
-}
-template <int DT> __device__ __forceinline__ uint16_t fs_from_f32(float v) {
-  if constexpr (DT == TS_F16) return __builtin_bit_cast(uint16_t, (_Float16)v);
-  else return __builtin_bit_cast(uint16_t, (__bf16)v);
-}
 
 #if defined(TS_TUNING) && defined(FS_TRACE)   // diagnostic builds only: per-wave phase time stamps (100 MHz), tools/trace_linear.py
 __device__ unsigned long long fs_trace_buf[4096 * 8];
@@ -102,15 +83,6 @@ __device__ __forceinline__ void fs_post_counter(fs_lds_int* c, int v, int lane) 
   __asm__ volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS traffic so far is done; vmcnt untouched
   if (lane == 0) __hip_atomic_store(c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// lgkmcnt(0) + s_barrier: what a wave owes the others at these barriers is its LDS traffic; its global loads (the compute
-// waves' ring, the loaders' next chunk / next image) stay in flight — __syncthreads() would add vmcnt(0)
-__device__ __forceinline__ void fs_barrier() {
-  __asm__ volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt / expcnt untouched
-  __builtin_amdgcn_s_barrier();
-  __asm__ volatile("" ::: "memory");
 }
 
 // The image of one tile (32 QH rows of x, whole K) -> LDS.  Piece (row, c) — c = 16-byte piece of the row — goes to unit

@@ -874,6 +874,7 @@ class LeanBertEncoder:
         # whole rows of the output (H <= 384: ts_linear_add_layernorm; the projection's output never goes to HBM)
         self.fused_output_layernorm = True
         self.gelu_in_down = True          # ... and the erf GELU between the two feed-forward projections inside the second
+        self.fused_mlp = True             # ... or, at hidden size 384, the whole feed-forward block as ONE kernel (ts_mlp_add_layernorm)
         for p in self.layers:
             p["tqkv"] = p["to"] = p["t1"] = p["to_ln"] = p["t2_ln"] = None
             if compute_dtype in (torch.bfloat16, torch.float16) and p["wqkv"].is_cuda:
@@ -960,8 +961,13 @@ class LeanBertEncoder:
         kernels when the activation is the erf GELU: the up projection writes its output BEFORE the activation and the
         down kernel applies the GELU while it stages its rows (the erf is vector-ALU work: in the up projection's epilogue
         it is exposed, beside the down projection's matrix instructions it is not).  Same bits either way."""
-        if tl and p["t1"] is not None and self.act is F.gelu and self.gelu_in_down:
-            return p["t2_ln"].add_layernorm(p["t1"](xb), x, *p["ln2"], gelu_input=True)
+        if tl and p["t1"] is not None and self.act is F.gelu:
+            if self.fused_mlp:
+                from .index import mlp_add_layernorm, mlp_usable
+                if mlp_usable(p["t1"], p["t2_ln"]):
+                    return mlp_add_layernorm(p["t1"], p["t2_ln"], xb, x, *p["ln2"])    # the whole block: one kernel
+            if self.gelu_in_down:
+                return p["t2_ln"].add_layernorm(p["t1"](xb), x, *p["ln2"], gelu_input=True)
         return p["t2_ln"].add_layernorm(self._up(p, xb, tl), x, *p["ln2"])
 
     def _up(self, p, xb, tl: bool):

@@ -635,6 +635,43 @@ def embed_layernorm(ids, pos_ids, type_ids, word, pos, typ, gamma, beta, eps: fl
     return out32, outlp
 
 
+def mlp_add_layernorm(up: "TiledLinear", down: "TiledLinear", x, residual, gamma, beta, eps: float, want_f32: bool = True):
+    """``LayerNorm(down(gelu(up(x))) + residual) * gamma + beta`` — BertIntermediate + BertOutput — in ONE kernel
+    (ts_mlp_add_layernorm): the intermediate never goes to HBM.  ``up`` [I, H] / ``down`` [H, I] are TiledLinear weights
+    (``mlp_usable(up, down)``), x [..., H] of their dtype, residual fp32 [..., H] or None, gamma / beta fp32 [H].  Returns
+    (y fp32 or None, y in the weights' dtype) — bit-identical to ``down.add_layernorm(up(x, gelu=True), residual, ...)``."""
+    torch = _torch()
+    if not mlp_usable(up, down):
+        raise ValueError("mlp_add_layernorm takes an up weight [I, 384] and a down weight [384, I] with I % 384 == 0 (mlp_usable)")
+    H = up.K
+    if x.dtype != up.dtype or x.shape[-1] != H or not x.is_contiguous() or x.device != up.device:
+        raise ValueError("x must be a contiguous [..., H] tensor of the weights' dtype on their device")
+    if residual is not None:
+        residual = residual.contiguous()
+        if residual.dtype != torch.float32 or residual.shape != x.shape or residual.device != x.device:
+            raise ValueError("residual must be float32 with x's shape on x's device")
+    gamma = gamma.detach().contiguous()
+    beta = beta.detach().contiguous() if beta is not None else None
+    for t in (gamma, beta):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != H or t.device != x.device):
+            raise ValueError("gamma / beta must be float32 [H] on x's device")
+    out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_f32 else None
+    outlp = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dev = x.device.index
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(_lib.load().ts_mlp_add_layernorm(ptr(up.tiled), ptr(up.bias), ptr(down.tiled), ptr(down.bias), ptr(x), ptr(residual),
+                                                ptr(gamma), ptr(beta), float(eps), _tensor_dtype(x), x.numel() // H, H, up.N,
+                                                ptr(out32), ptr(outlp), dev, ctypes.c_void_p(_stream_ptr(dev))))
+    return out32, outlp
+
+
+def mlp_usable(up, down) -> bool:
+    """Whether ``mlp_add_layernorm`` takes this pair of TiledLinear weights: hidden size 384 (a workgroup owns whole rows),
+    intermediate size a multiple of 384, same dtype and device."""
+    return (up is not None and down is not None and up.K == 384 and down.N == 384 and up.N == down.K and up.N % 384 == 0
+            and up.dtype == down.dtype and up.device == down.device)
+
+
 class TiledLinear:
     """A torch.nn.Linear-style weight [N, K] (fp16 / bf16, on the GPU) re-tiled once for ts_linear_act: ``y = act(x W^T + b)``
     with the weight streamed from L2 and x's rows in LDS — for reduction dimensions up to 384 (MiniLM-class encoders), where
