@@ -650,6 +650,37 @@ def test_packed_batches_equal_padded_batches():
         assert float((b - ref).abs().max()) < 4e-3
 
 
+def test_projection_kernels_are_repeatable_bit_for_bit():
+    """The streamed-weight kernels hand data between waves through LDS with counters (ffn_stream_kernel's slots), bare
+    barriers with rings in flight (proj_ln_kernel, mlp_ln_kernel) and an LDS table built at run time: 200 launches of each
+    on the same input must give the same bits every time (a lost ordering shows up as a rare different value), at a size
+    with several tiles per compute unit."""
+    import torch
+    from tristage_rag_amd.index import TiledLinear, mlp_add_layernorm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, H, I = 70001, 384, 1536
+    x = (torch.randn((M, H), generator=g, device="cuda") * 0.8).to(torch.bfloat16)
+    w1 = (torch.randn((I, H), generator=g, device="cuda") * 0.06).to(torch.bfloat16)
+    b1 = (torch.randn((I,), generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+    w2 = (torch.randn((H, I), generator=g, device="cuda") * 0.03).to(torch.bfloat16)
+    b2 = (torch.randn((H,), generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn((M, H), generator=g, device="cuda")
+    gamma = 1.0 + 0.1 * torch.randn((H,), generator=g, device="cuda")
+    beta = 0.1 * torch.randn((H,), generator=g, device="cuda")
+    up, down = TiledLinear(w1, b1), TiledLinear(w2, b2, with_layernorm=True)
+    first = None
+    for _ in range(200):
+        u = up(x, gelu=True)
+        d32, dlp = down.add_layernorm(u, res, gamma, beta, 1e-12)
+        m32, mlp = mlp_add_layernorm(up, down, x, res, gamma, beta, 1e-12)
+        now = (u, d32, dlp, m32, mlp)
+        if first is None:
+            first = now
+            assert torch.equal(d32, m32) and torch.equal(dlp, mlp)
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, now))
+
+
 def test_rrf_fusion_on_the_gpu_is_bit_identical_to_the_host_code():
     """Stage1Retriever._fuse_rrf_device (one stable float64 sort for a whole query batch) against _fuse_arrays per query
     (itself pinned to the reference's dictionary code on the CPU): same ids, same float64 scores, same tie order —
