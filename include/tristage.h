@@ -244,8 +244,8 @@ int ts_maxsim_indexed_batch(const void* q, const int32_t* q_off, int32_t nq, con
  * ts_bm25_search: term_ids = query tokens as vocabulary ids in query order (host);
  * writes up to k (score, doc) pairs to HOST arrays; *n_out < k means all documents
  * with a non-zero score were returned (the rest score exactly 0.0).  A ts_bm25
- * handle keeps ONE accumulator / candidate workspace: calls on one handle must not
- * overlap (one caller at a time; different handles are independent).            */
+ * handle keeps ONE set of accumulator / candidate workspaces: calls on one handle must
+ * not overlap (one caller at a time; different handles are independent).        */
 typedef struct ts_bm25 ts_bm25;
 int ts_bm25_create(int32_t device, ts_bm25** out);
 int ts_bm25_destroy(ts_bm25* h);
@@ -257,7 +257,10 @@ int ts_bm25_search(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t
 /* The same for nq queries with ONE synchronisation: query q's terms are
  * term_ids[term_off[q] .. term_off[q+1]) (host arrays; term_off has nq+1 entries), its
  * results out_scores / out_ids [q*k .. q*k + n_out[q]).  Each query is scored exactly as by
- * ts_bm25_search (same kernels, same order of additions), one after the other on `stream`. */
+ * ts_bm25_search (same kernels, same order of additions per query); the queries of a batch
+ * run side by side — one launch per token position for up to 64 of them, each with its own
+ * accumulator (20 bytes per document and query, at most 4 GiB per handle) — instead of one
+ * chain of launches per query.                                                           */
 int ts_bm25_search_batch(ts_bm25* h, const int32_t* term_ids, const int64_t* term_off, int32_t nq,
                          int32_t k, double* out_scores, int64_t* out_ids, int32_t* n_out,
                          void* stream);

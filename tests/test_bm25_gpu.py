@@ -63,8 +63,10 @@ def test_gpu_bm25_equals_host_bm25_on_a_larger_corpus():
 
 
 def test_gpu_bm25_batch_equals_single_queries():
-    """BM25Index.search_many (ts_bm25_search_batch: one call, one synchronisation) == search() per query, bit for
-    bit, including queries without a known term, repeated queries, and a batch after a batch (state left clean)."""
+    """BM25Index.search_many (ts_bm25_search_batch: one call, one synchronisation, the queries side by side in up to 64
+    lanes — one launch per token position) == search() per query, bit for bit, including queries without a known term,
+    repeated queries, lanes with long and short posting lists in the same launch, more queries than lanes, and a batch
+    after a batch (state left clean)."""
     from tristage_rag_amd.stage1_retriever import BM25Index
     rng = np.random.default_rng(9)
     vocab = [f"w{i}" for i in range(300)]
@@ -75,7 +77,7 @@ def test_gpu_bm25_batch_equals_single_queries():
     host.fit(docs)
     gpu.fit(docs)
     queries = ["w0 w1 w2", "zzz", "w299", "", "w0", "w5 w5 w17 nosuch", "w0 w1 w2"] + \
-              [" ".join(rng.choice(vocab, size=int(rng.integers(1, 9)))) for _ in range(57)]
+              [" ".join(rng.choice(vocab, size=int(rng.integers(1, 9)))) for _ in range(80)]   # 87 queries: two chunks of lanes
     for k in (10, 300):
         for _ in range(2):
             many = gpu.search_many(queries, k)

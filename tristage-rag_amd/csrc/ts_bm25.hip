@@ -42,12 +42,18 @@ struct ts_bm25 {
   float* post_tf = nullptr;
   double* idf = nullptr;       // [V]
   double* len_norm = nullptr;  // [N]  k1*(1-b+b*len/avg)
-  double* acc = nullptr;       // [N], all zero between queries
-  int32_t* touched = nullptr;  // [N]
-  uint32_t* counters = nullptr;  // [0] n_touched, [1] n_out, [2] n_cand, [3] 1 = candidates usable
-  uint64_t* keys = nullptr;    // [N] score keys of the touched documents (pre-filter)
-  int32_t* cand = nullptr;     // [BM_CAND_CAP]
-  uint64_t* tau = nullptr;     // [1]
+  // LANES: `lanes` independent sets of the per-query workspace, so that a batch of queries runs as ONE launch per token
+  // position (blockIdx.y = lane) instead of one chain of launches per query; lane y's arrays start at y * N (acc, touched,
+  // keys), y * 4 (counters), y * BM_CAND_CAP (cand), y (tau).
+  int lanes = 0;
+  double* acc = nullptr;       // [lanes][N], all zero between queries
+  int32_t* touched = nullptr;  // [lanes][N]
+  uint32_t* counters = nullptr;  // [lanes][4]: [0] n_touched, [1] n_out, [2] n_cand, [3] 1 = candidates usable
+  uint64_t* keys = nullptr;    // [lanes][N] score keys of the touched documents (pre-filter)
+  int32_t* cand = nullptr;     // [lanes][BM_CAND_CAP]
+  uint64_t* tau = nullptr;     // [lanes]
+  void* steps = nullptr;       // device copy of a batch's per-(token position, lane) posting ranges
+  size_t steps_bytes = 0;
   double* out_s = nullptr;     // [BM_MAX_K]
   int32_t* out_i = nullptr;    // [BM_MAX_K]
   int64_t* term_off = nullptr;  // host copy [V+1]
@@ -70,13 +76,22 @@ struct Guard {
 };
 }  // namespace
 
+// One token position of every lane's query: lane y = blockIdx.y adds the postings of ITS token (st[y]: offset, length, idf;
+// length 0 = this query has no token at this position).  Within a lane the launches follow each other in query order and a
+// token's postings hit distinct documents: the same additions in the same order as one query at a time.
+struct BmStep { int64_t off, df; double idf; };
 __global__ void bm25_accumulate(const int32_t* __restrict__ post_doc, const float* __restrict__ post_tf,
-                                int64_t off, int64_t df, double idf, double k1p1,
+                                const BmStep* __restrict__ st, double k1p1, int64_t N,
                                 const double* __restrict__ len_norm, double* __restrict__ acc,
-                                int32_t* __restrict__ touched, uint32_t* __restrict__ n_touched) {
+                                int32_t* __restrict__ touched, uint32_t* __restrict__ counters) {
   // no fused multiply-add here: the reference computes idf*(num/den) and the running
   // sum with one rounding per operation (CPython floats), and hipcc contracts by default
 #pragma clang fp contract(off)
+  const int y = blockIdx.y;
+  const int64_t off = st[y].off, df = st[y].df;
+  const double idf = st[y].idf;
+  acc += (size_t)y * N; touched += (size_t)y * N;
+  uint32_t* n_touched = counters + 4 * y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= df) return;
   const int32_t d = post_doc[off + i];
@@ -87,9 +102,11 @@ __global__ void bm25_accumulate(const int32_t* __restrict__ post_doc, const floa
   if (old == 0.0) touched[atomicAdd(n_touched, 1u)] = d;  // contributions are > 0: first touch
 }
 
-__global__ void bm25_reset(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
-                           double* __restrict__ acc) {
-  const uint32_t n = *n_touched;
+__global__ void bm25_reset(const int32_t* __restrict__ touched, const uint32_t* __restrict__ counters,
+                           double* __restrict__ acc, int64_t N) {
+  const int y = blockIdx.y;
+  touched += (size_t)y * N; acc += (size_t)y * N;
+  const uint32_t n = counters[4 * y];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     acc[touched[i]] = 0.0;
 }
@@ -132,21 +149,24 @@ __device__ __forceinline__ bool key_ge(uint64_t sk, uint32_t dk, uint64_t tsk, u
 }
 
 // ---- pre-filter for long touched lists --------------------------------------------------
-__global__ void bm25_keys(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
-                          const double* __restrict__ acc, uint64_t* __restrict__ keys) {
-  const uint32_t n = *n_touched;
+__global__ void bm25_keys(const int32_t* __restrict__ touched, const uint32_t* __restrict__ counters,
+                          const double* __restrict__ acc, uint64_t* __restrict__ keys, int64_t N) {
+  const int y = blockIdx.y;
+  touched += (size_t)y * N; acc += (size_t)y * N; keys += (size_t)y * N;
+  const uint32_t n = counters[4 * y];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     keys[i] = d2key(acc[touched[i]]);
 }
 
 // one workgroup: tau = the m-th best of BM_SAMPLE strided keys, m ~ 4k * sample / n
-__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_tau(const uint64_t* __restrict__ keys,
-                                                           const uint32_t* __restrict__ n_touched, int k,
+__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_tau(const uint64_t* __restrict__ keys, int k,
                                                            uint64_t* __restrict__ tau,
-                                                           uint32_t* __restrict__ counters) {
+                                                           uint32_t* __restrict__ counters, int64_t N) {
   __shared__ uint64_t sk[BM_SAMPLE];
   const int tid = threadIdx.x;
-  const uint32_t n = *n_touched;
+  const int y = blockIdx.y;
+  keys += (size_t)y * N; tau += y; counters += 4 * y;
+  const uint32_t n = counters[0];
   if (tid == 0) { counters[2] = 0; counters[3] = 0; }
   if (n <= BM_PRE_MIN) {          // short list: the exact select takes it as it is
     if (tid == 0) *tau = ~0ull;
@@ -175,11 +195,13 @@ __global__ __launch_bounds__(BM_SEL_THREADS) void bm25_tau(const uint64_t* __res
   }
 }
 
-__global__ void bm25_filter(const int32_t* __restrict__ touched, const uint32_t* __restrict__ n_touched,
-                            const uint64_t* __restrict__ keys, const uint64_t* __restrict__ tau,
-                            int32_t* __restrict__ cand, uint32_t* __restrict__ counters) {
+__global__ void bm25_filter(const int32_t* __restrict__ touched, const uint64_t* __restrict__ keys,
+                            const uint64_t* __restrict__ tau, int32_t* __restrict__ cand,
+                            uint32_t* __restrict__ counters, int64_t N) {
+  const int y = blockIdx.y;
+  touched += (size_t)y * N; keys += (size_t)y * N; tau += y; cand += (size_t)y * BM_CAND_CAP; counters += 4 * y;
   if (counters[3] == 0) return;
-  const uint32_t n = *n_touched;
+  const uint32_t n = counters[0];
   const uint64_t t = *tau;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     if (keys[i] >= t) {
@@ -192,19 +214,25 @@ __global__ void bm25_filter(const int32_t* __restrict__ touched, const uint32_t*
 // one workgroup: exact top-k of the documents in `touched` (the whole touched list, or the
 // candidate list of the pre-filter).  use_cand: 1 = run only if the candidate list is usable
 // (it holds at least min(k, n_touched) documents and did not overflow); 0 = run only if it is not.
-__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_select(const int32_t* __restrict__ touched,
-                                                              const uint32_t* __restrict__ n_touched,
+// Lane y = blockIdx.y: the list is the lane's candidate list (use_cand 1) or its touched list (0); results go to row y of
+// out_s / out_i [lanes, k] and the count to n_out[y].
+__global__ __launch_bounds__(BM_SEL_THREADS) void bm25_select(const int32_t* __restrict__ touched_all,
+                                                              const int32_t* __restrict__ cand_all,
                                                               const double* __restrict__ acc, int k,
                                                               double* __restrict__ out_s,
                                                               int32_t* __restrict__ out_i,
                                                               uint32_t* __restrict__ n_out,
                                                               const uint32_t* __restrict__ counters,
-                                                              int use_cand) {
+                                                              int use_cand, int64_t N) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t sh[8];
   __shared__ uint64_t ssk[BM_MAX_K];
   __shared__ uint32_t sdk[BM_MAX_K];
   const int tid = threadIdx.x;
+  const int y = blockIdx.y;
+  counters += 4 * y; acc += (size_t)y * N; out_s += (size_t)y * k; out_i += (size_t)y * k; n_out += y;
+  const int32_t* touched = use_cand ? cand_all + (size_t)y * BM_CAND_CAP : touched_all + (size_t)y * N;
+  const uint32_t* n_touched = use_cand ? counters + 2 : counters;
   const uint32_t n_all = counters[0];
   const uint32_t kk = (uint32_t)k < n_all ? (uint32_t)k : n_all;
   const bool cand_ok = counters[3] != 0 && counters[2] >= kk && counters[2] <= BM_CAND_CAP;
@@ -305,10 +333,11 @@ extern "C" int ts_bm25_create(int32_t device, ts_bm25** out) {
 
 static void bm25_free(ts_bm25* h) {
   void* bufs[] = {h->post_doc, h->post_tf, h->idf, h->len_norm, h->acc, h->touched, h->counters, h->out_s, h->out_i,
-                  h->keys, h->cand, h->tau, h->batch_buf};
+                  h->keys, h->cand, h->tau, h->batch_buf, h->steps};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   h->batch_buf = nullptr; h->batch_bytes = 0;
+  h->steps = nullptr; h->steps_bytes = 0; h->lanes = 0;
   h->post_doc = nullptr; h->post_tf = nullptr; h->idf = nullptr; h->len_norm = nullptr; h->acc = nullptr;
   h->touched = nullptr; h->counters = nullptr; h->out_s = nullptr; h->out_i = nullptr;
   h->keys = nullptr; h->cand = nullptr; h->tau = nullptr;
@@ -322,6 +351,27 @@ extern "C" int ts_bm25_destroy(ts_bm25* h) {
   (void)hipDeviceSynchronize();
   bm25_free(h);
   delete h;
+  return TS_OK;
+}
+
+// (Re)allocates the per-query workspace for `lanes` lanes, zeroed.  No launch may be pending on the handle.
+#define BM_LANE_BUDGET (4ull << 30)   // bytes of lane workspace a handle may hold (20 bytes per document and lane)
+static int bm25_set_lanes(ts_bm25* h, int lanes) {
+  void* old[] = {h->acc, h->touched, h->counters, h->keys, h->cand, h->tau};
+  for (void* b : old)
+    if (b) (void)hipFree(b);
+  h->acc = nullptr; h->touched = nullptr; h->counters = nullptr; h->keys = nullptr; h->cand = nullptr; h->tau = nullptr;
+  h->lanes = 0;
+  const size_t n1 = (size_t)(h->N > 0 ? h->N : 1) * (size_t)lanes;
+  TS_HIP(hipMalloc((void**)&h->acc, n1 * 8));
+  TS_HIP(hipMalloc((void**)&h->touched, n1 * 4));
+  TS_HIP(hipMalloc((void**)&h->counters, (size_t)lanes * 16));
+  TS_HIP(hipMalloc((void**)&h->keys, n1 * 8));
+  TS_HIP(hipMalloc((void**)&h->cand, (size_t)lanes * BM_CAND_CAP * 4));
+  TS_HIP(hipMalloc((void**)&h->tau, (size_t)lanes * 8));
+  TS_HIP(hipMemset(h->acc, 0, n1 * 8));
+  TS_HIP(hipMemset(h->counters, 0, (size_t)lanes * 16));
+  h->lanes = lanes;
   return TS_OK;
 }
 
@@ -347,59 +397,74 @@ extern "C" int ts_bm25_set_index(ts_bm25* h, int64_t N, int64_t V, int64_t nnz, 
   TS_HIP(hipMalloc((void**)&h->post_doc, z1 * 4));
   TS_HIP(hipMalloc((void**)&h->post_tf, z1 * 4));
   TS_HIP(hipMalloc((void**)&h->len_norm, n1 * 8));
-  TS_HIP(hipMalloc((void**)&h->acc, n1 * 8));
-  TS_HIP(hipMalloc((void**)&h->touched, n1 * 4));
-  TS_HIP(hipMalloc((void**)&h->counters, 64));
   TS_HIP(hipMalloc((void**)&h->out_s, BM_MAX_K * 8));
   TS_HIP(hipMalloc((void**)&h->out_i, BM_MAX_K * 4));
-  TS_HIP(hipMalloc((void**)&h->keys, n1 * 8));
-  TS_HIP(hipMalloc((void**)&h->cand, (size_t)BM_CAND_CAP * 4));
-  TS_HIP(hipMalloc((void**)&h->tau, 8));
+  TS_CHECK(bm25_set_lanes(h, 1));
   if (nnz) {
     TS_HIP(hipMemcpy(h->post_doc, post_doc, (size_t)nnz * 4, hipMemcpyHostToDevice));
     TS_HIP(hipMemcpy(h->post_tf, post_tf, (size_t)nnz * 4, hipMemcpyHostToDevice));
   }
   if (N) TS_HIP(hipMemcpy(h->len_norm, len_norm, (size_t)N * 8, hipMemcpyHostToDevice));
-  TS_HIP(hipMemset(h->acc, 0, n1 * 8));
-  TS_HIP(hipMemset(h->counters, 0, 64));
   return TS_OK;
 }
 
 // term_ids: the query's tokens mapped to vocabulary ids, in query order (unknown
 // tokens dropped, repeats kept).  Writes up to k (score, doc) pairs, best first;
 // *n_out < k means every document with a non-zero score is in the output.
-// One query's launches; results land in out_s / out_i (device, k entries) and its count in *cnt_out (device); the
-// accumulator, the touched list and the counters are back to zero afterwards.  Everything is stream-ordered.
-static int bm25_enqueue_query(ts_bm25* h, const int32_t* term_ids, int32_t n_terms, int32_t k, double* out_s,
-                              int32_t* out_i, uint32_t* cnt_out, hipStream_t s) {
-  int64_t total_df = 0;
-  for (int i = 0; i < n_terms; ++i) {
-    const int32_t t = term_ids[i];
-    if (t < 0 || t >= h->V) { ts_set_error("term id %d out of range", t); return TS_ERR_INVALID; }
-    const int64_t off = h->term_off[t], df = h->term_off[t + 1] - off;
-    if (df <= 0) continue;
-    total_df += df;
-    const int64_t blocks = (df + 255) / 256;
-    hipLaunchKernelGGL(bm25_accumulate, dim3((unsigned)blocks), dim3(256), 0, s, h->post_doc, h->post_tf,
-                       off, df, h->idf_host[t], h->k1p1, h->len_norm, h->acc, h->touched, h->counters);
+// A chunk of up to h->lanes queries (query q0 + y in lane y): one bm25_accumulate launch per token position, then the
+// pre-filter (if some lane's postings are long enough to need it) and the two select launches, all with blockIdx.y = lane;
+// results land in rows q0 .. of bs / bi / bc (device).  Accumulators, touched lists and counters are back to zero afterwards.
+// Everything is stream-ordered; `st_host` / `st_dev` hold this chunk's [positions][lanes] posting ranges.
+static int bm25_enqueue_chunk(ts_bm25* h, const int32_t* term_ids, const int64_t* term_off, int q0, int nl, int32_t k,
+                              double* bs, int32_t* bi, uint32_t* bc, BmStep* st_host, BmStep* st_dev, hipStream_t s) {
+  const int L = h->lanes;
+  int64_t max_terms = 0, max_total = 0;
+  for (int y = 0; y < nl; ++y) max_terms = std::max<int64_t>(max_terms, term_off[q0 + y + 1] - term_off[q0 + y]);
+  std::vector<int64_t> max_df((size_t)max_terms, 0);
+  for (int y = 0; y < nl; ++y) {
+    const int32_t* t = term_ids + term_off[q0 + y];
+    const int64_t nt = term_off[q0 + y + 1] - term_off[q0 + y];
+    int64_t total = 0;
+    for (int64_t i = 0; i < max_terms; ++i) {
+      BmStep& e = st_host[(size_t)i * L + y];
+      e.off = 0; e.df = 0; e.idf = 0.0;
+      if (i >= nt) continue;
+      if (t[i] < 0 || t[i] >= h->V) { ts_set_error("term id %d out of range", t[i]); return TS_ERR_INVALID; }
+      e.off = h->term_off[t[i]];
+      e.df = h->term_off[t[i] + 1] - e.off;
+      e.idf = h->idf_host[t[i]];
+      if (e.df < 0) e.df = 0;
+      total += e.df;
+      max_df[(size_t)i] = std::max(max_df[(size_t)i], e.df);
+    }
+    max_total = std::max(max_total, total);
   }
-  if (total_df > BM_PRE_MIN) {
-    // long touched list (its length is only known on the device; the postings' total bounds it)
-    const int blocks = (int)std::min<int64_t>(1024, (total_df + 255) / 256);
-    hipLaunchKernelGGL(bm25_keys, dim3(blocks), dim3(256), 0, s, h->touched, h->counters, h->acc, h->keys);
-    hipLaunchKernelGGL(bm25_tau, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->keys, h->counters, k, h->tau, h->counters);
-    hipLaunchKernelGGL(bm25_filter, dim3(blocks), dim3(256), 0, s, h->touched, h->counters, h->keys, h->tau,
-                       h->cand, h->counters);
-    hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->cand, h->counters + 2, h->acc, k,
-                       out_s, out_i, h->counters + 1, h->counters, 1);
+  for (int y = nl; y < L; ++y)
+    for (int64_t i = 0; i < max_terms; ++i) st_host[(size_t)i * L + y] = BmStep{0, 0, 0.0};
+  if (max_terms)
+    TS_HIP(hipMemcpyAsync(st_dev, st_host, (size_t)max_terms * L * sizeof(BmStep), hipMemcpyHostToDevice, s));
+  for (int64_t i = 0; i < max_terms; ++i) {
+    if (max_df[(size_t)i] <= 0) continue;
+    const int64_t blocks = (max_df[(size_t)i] + 255) / 256;
+    hipLaunchKernelGGL(bm25_accumulate, dim3((unsigned)blocks, (unsigned)nl), dim3(256), 0, s, h->post_doc, h->post_tf,
+                       st_dev + (size_t)i * L, h->k1p1, h->N, h->len_norm, h->acc, h->touched, h->counters);
   }
-  // (runs only when the candidate list was not made or is not usable)
-  hipLaunchKernelGGL(bm25_select, dim3(1), dim3(BM_SEL_THREADS), 0, s, h->touched, h->counters, h->acc, k,
-                     out_s, out_i, h->counters + 1, h->counters, 0);
+  if (max_total > BM_PRE_MIN) {
+    // long touched lists (their lengths are only known on the device; a lane's postings' total bounds its list; a lane
+    // whose list is short is left alone by bm25_tau: tau = all ones, "candidates usable" stays 0)
+    const int blocks = (int)std::min<int64_t>(1024, (max_total + 255) / 256);
+    hipLaunchKernelGGL(bm25_keys, dim3(blocks, nl), dim3(256), 0, s, h->touched, h->counters, h->acc, h->keys, h->N);
+    hipLaunchKernelGGL(bm25_tau, dim3(1, nl), dim3(BM_SEL_THREADS), 0, s, h->keys, k, h->tau, h->counters, h->N);
+    hipLaunchKernelGGL(bm25_filter, dim3(blocks, nl), dim3(256), 0, s, h->touched, h->keys, h->tau, h->cand, h->counters, h->N);
+    hipLaunchKernelGGL(bm25_select, dim3(1, nl), dim3(BM_SEL_THREADS), 0, s, h->touched, h->cand, h->acc, k,
+                       bs + (size_t)q0 * k, bi + (size_t)q0 * k, bc + q0, h->counters, 1, h->N);
+  }
+  // (a lane runs this one only when its candidate list was not made or is not usable)
+  hipLaunchKernelGGL(bm25_select, dim3(1, nl), dim3(BM_SEL_THREADS), 0, s, h->touched, h->cand, h->acc, k,
+                     bs + (size_t)q0 * k, bi + (size_t)q0 * k, bc + q0, h->counters, 0, h->N);
+  hipLaunchKernelGGL(bm25_reset, dim3(256, nl), dim3(256), 0, s, h->touched, h->counters, h->acc, h->N);
   TS_HIP(hipGetLastError());
-  TS_HIP(hipMemcpyAsync(cnt_out, h->counters + 1, 4, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
-  TS_HIP(hipMemsetAsync(h->counters, 0, 16, s));
+  TS_HIP(hipMemsetAsync(h->counters, 0, (size_t)L * 16, s));
   return TS_OK;
 }
 
@@ -410,16 +475,28 @@ extern "C" int ts_bm25_search_batch(ts_bm25* h, const int32_t* term_ids, const i
     return TS_ERR_INVALID;
   }
   if (k > BM_MAX_K) { ts_set_error("bm25 top_k %d exceeds %d", k, BM_MAX_K); return TS_ERR_UNSUPPORTED; }
+  int64_t max_terms = 0;
   for (int q = 0; q < nq; ++q) {
     n_out[q] = 0;
     if (term_off[q + 1] < term_off[q] || (term_off[q + 1] > term_off[q] && !term_ids)) {
       ts_set_error("bad term offsets in bm25_search_batch");
       return TS_ERR_INVALID;
     }
+    max_terms = std::max(max_terms, term_off[q + 1] - term_off[q]);
   }
   if (nq == 0 || h->N == 0) return TS_OK;
   Guard g(h->device);
   hipStream_t s = (hipStream_t)stream;
+  // lanes: as many as the batch has queries, within the workspace budget (64 at most)
+  {
+    const size_t per_lane = (size_t)h->N * 20 + (size_t)BM_CAND_CAP * 4 + 32;
+    int want = (int)std::min<int64_t>(std::min<int64_t>(nq, 64), std::max<int64_t>(1, (int64_t)(BM_LANE_BUDGET / per_lane)));
+    if (want > h->lanes) {
+      TS_HIP(hipStreamSynchronize(s));
+      TS_CHECK(bm25_set_lanes(h, want));
+    }
+  }
+  const int L = h->lanes;
   // per-batch result buffers (device): [nq, k] scores, [nq, k] ids, [nq] counts — one copy back and ONE sync per batch
   const size_t need = (size_t)nq * k * 12 + (size_t)nq * 4;
   if (need > h->batch_bytes) {
@@ -428,19 +505,28 @@ extern "C" int ts_bm25_search_batch(ts_bm25* h, const int32_t* term_ids, const i
     TS_HIP(hipMalloc(&h->batch_buf, need));
     h->batch_bytes = need;
   }
+  const int nchunks = (nq + L - 1) / L;
+  const size_t st_count = (size_t)std::max<int64_t>(max_terms, 1) * L;
+  if ((size_t)nchunks * st_count * sizeof(BmStep) > h->steps_bytes) {
+    if (h->steps) (void)hipFree(h->steps);
+    h->steps = nullptr; h->steps_bytes = 0;
+    TS_HIP(hipMalloc(&h->steps, (size_t)nchunks * st_count * sizeof(BmStep)));
+    h->steps_bytes = (size_t)nchunks * st_count * sizeof(BmStep);
+  }
+  std::vector<BmStep> st_host((size_t)nchunks * st_count);   // (alive until the synchronisation below: source of async copies)
   double* bs = reinterpret_cast<double*>(h->batch_buf);
   int32_t* bi = reinterpret_cast<int32_t*>(bs + (size_t)nq * k);
   uint32_t* bc = reinterpret_cast<uint32_t*>(bi + (size_t)nq * k);
   TS_HIP(hipMemsetAsync(bc, 0, (size_t)nq * 4, s));
   int st = TS_OK;
-  for (int q = 0; q < nq && st == TS_OK; ++q) {
-    const int64_t nt = term_off[q + 1] - term_off[q];
-    if (nt == 0) continue;
-    st = bm25_enqueue_query(h, term_ids + term_off[q], (int32_t)nt, k, bs + (size_t)q * k, bi + (size_t)q * k, bc + q, s);
+  for (int c = 0; c < nchunks && st == TS_OK; ++c) {
+    const int q0 = c * L, nl = std::min(L, nq - q0);
+    st = bm25_enqueue_chunk(h, term_ids, term_off, q0, nl, k, bs, bi, bc, st_host.data() + (size_t)c * st_count,
+                            reinterpret_cast<BmStep*>(h->steps) + (size_t)c * st_count, s);
   }
-  if (st != TS_OK) {   // a bad term id part-way: leave the handle clean (accumulator / counters) before reporting it
-    hipLaunchKernelGGL(bm25_reset, dim3(256), dim3(256), 0, s, h->touched, h->counters, h->acc);
-    (void)hipMemsetAsync(h->counters, 0, 16, s);
+  if (st != TS_OK) {   // a bad term id part-way: leave the handle clean (accumulators / counters) before reporting it
+    hipLaunchKernelGGL(bm25_reset, dim3(256, L), dim3(256), 0, s, h->touched, h->counters, h->acc, h->N);
+    (void)hipMemsetAsync(h->counters, 0, (size_t)L * 16, s);
     (void)hipStreamSynchronize(s);
     return st;
   }
