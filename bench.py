@@ -300,11 +300,13 @@ def pipeline_legs(torch):
     (cross-encoder on cached token ids) top-10, bf16, 256 queries through RetrievalPipeline.search_many in calls of
     64 — with randomly initialised models of the reference's architectures (no weights exist offline: throughput
     only), once as the benchmark configuration has it (dense stage 1) and once with the reference's default
-    BM25 + RRF fusion.  Exactly bench_pipeline.py's settings for its headline line."""
+    BM25 + RRF fusion.  Exactly bench_pipeline.py's settings for its headline line (`--store --many 64 --ids --graphs`: the
+    batched query forwards of stages 1 and 2 are replayed from HIP graphs — launch-bound otherwise — and give the eager
+    results, tests/test_pipeline_gpu.py::test_hip_graph_query_forwards_match_eager)."""
     import bench_pipeline
     out = {}
     for name, extra in (("pipeline_search_many_qps", []), ("pipeline_search_many_bm25_rrf_qps", ["--bm25"])):
-        r = bench_pipeline.run(bench_pipeline.parse_args(["--queries", "256", "--store", "--many", "64", "--ids"] + extra))
+        r = bench_pipeline.run(bench_pipeline.parse_args(["--queries", "256", "--store", "--many", "64", "--ids", "--graphs"] + extra))
         out[name] = r["value"]
         out[name.replace("_qps", "_stage_ms_per_query")] = {k.replace("_time", ""): round(v * 1e3, 4)
                                                              for k, v in r["mean_stage_seconds"].items()}

@@ -32,7 +32,7 @@ def parse_args(argv=None):
     ap.add_argument("--cache", action="store_true", help="cache stage-2 token matrices per document")
     ap.add_argument("--store", action="store_true",
                     help="stage-2 token store filled at add time, read in place by ts_maxsim_indexed")
-    ap.add_argument("--graphs", action="store_true", help="replay the batch-1 query forwards from HIP graphs")
+    ap.add_argument("--graphs", action="store_true", help="replay the query forwards (one query, or a search_many batch padded to a bucket) from HIP graphs")
     ap.add_argument("--bm25", action="store_true", help="BM25 + RRF fusion in stage 1, like the reference's default")
     ap.add_argument("--cprofile", action="store_true", help="print the host-side hot spots of the timed region (stderr)")
     ap.add_argument("--ids", action="store_true",
