@@ -616,8 +616,9 @@ def test_packed_batches_equal_padded_batches():
     # the assembled pairs
     docs = _corpus(400)
     queries = ["neural network attention", "gpu memory index retrieval system", "token"]
-    for spec in ("random:minilm", "random:xlmr-large:64:2:2"):
-        ce = CrossEncoderModel(spec, device="cuda", use_amp=True)
+    # (the third: the reference's own GPU AMP type, fp16 — the feed-forward kernel computes its GELU there, no table)
+    for spec, amp in (("random:minilm", torch.bfloat16), ("random:xlmr-large:64:2:2", torch.bfloat16), ("random:minilm", torch.float16)):
+        ce = CrossEncoderModel(spec, device="cuda", use_amp=True, amp_dtype=amp)
         pa = PairAssembler(ce.tokenizer, 64)
         pa.add_documents(docs)
         n = 500
