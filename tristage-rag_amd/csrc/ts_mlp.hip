@@ -14,8 +14,9 @@
 //     the half-wave exchange IS a piece of that image;  down(c): the chunk image x W2's chunk c into the output accumulators;
 //   * the erf GELU is vector-ALU work (~72 issue cycles per value): chunk c's runs INSIDE down(c - 1), two values per k
 //     group between the MFMAs of the same wave, where an MFMA leaves 24 of its 32 cycles of vector issue free
-//     (MI355X_MICROARCH.md, constants table) — so the phase order is up(0) G(0) | up(1) [down(0) + G(1)] | up(2) [down(1) +
-//     G(2)] | ... | down(last), with two barriers per chunk around the image write;
+//     (MI355X_MICROARCH.md, constants table), chunk 0's inside up(1) — so the phase order is up(0) [up(1) + G(0)] |
+//     [down(0) + G(1)] up(2) | [down(1) + G(2)] up(3) | ... | down(last), with two barriers per chunk around the image write
+//     (one for chunk 0);
 //   * no loader waves (there is nothing to load after the prologue but the residual), so 12 waves = 3 per SIMD = 168 registers:
 //     both accumulator sets (96), the ring (32) and the B operands fit;
 //   * the output tile is staged in LDS as 16-bit values where the images were and the LayerNorm rows are run by all waves
@@ -234,57 +235,63 @@ __global__ __launch_bounds__(64 * ML_WAVES) void mlp_ln_kernel(MlParams p) {
   const u32x4* xq1 = ximg + (lane ^ ((2 + h) << 2));
   const u32x4* dq0 = dimg + (lane ^ (h << 2));
   const u32x4* dq1 = dimg + (lane ^ ((2 + h) << 2));
-  f32x16 accd[ML_QH];
-  uint32_t pk[ML_QH][8];                                     // the current chunk's up output (this wave's block), packed pairs
-#pragma unroll
-  for (int hq = 0; hq < ML_QH; ++hq)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accd[hq][r] = 0.f;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
+  f32x16 accd[ML_QH], accu[ML_QH];   // (neither is zeroed: a set's first MFMAs take no accumulator input — FRESH)
+  uint32_t pk[ML_QH][8];             // a chunk's up output (this wave's block) + bias, rounded, packed pairs; activated in place
+  // + bias, rounded to the 16-bit type (the linear's output), packed: accu -> pk
+  auto pack = [&](int c) {
     const MlBias b1 = ml_load_bias(p.b1, c * ML_WAVES + wave);   // bias of this chunk's block of the intermediate
-    const u32x4* up_w = w1 + (size_t)(c * ML_WAVES + wave) * ML_KGC * 64;
-    // ---- up(c): after it comes up(1) (c = 0: chunk 0's activation has no down phase to run under) or down(c - 1)
-    {
-      f32x16 accu[ML_QH];                                    // (no zeroing: the phase's first MFMAs take no accumulator input)
-      const u32x4* nxt = c > 0 ? w2 + (size_t)(c - 1) * ML_KGC * 64 : NCH > 1 ? w1 + (size_t)(ML_WAVES + wave) * ML_KGC * 64 : w2;
-      ml_phase<DT, false, true>(accu, ring, up_w, nxt, xq0, xq1, pk, lane, tab);
-      // + bias, rounded to the 16-bit type (the linear's output), packed — chunk 0 with its activation at once (it has no
-      // down phase to run under)
-      if (c == 0) ML_STAMP(3);
 #pragma unroll
-      for (int hq = 0; hq < ML_QH; ++hq)
+    for (int hq = 0; hq < ML_QH; ++hq)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t w = (uint32_t)fs_from_f32<DT>(accu[hq][2 * k] + ml_bias<DT>(b1, 2 * k, h)) |
-                             ((uint32_t)fs_from_f32<DT>(accu[hq][2 * k + 1] + ml_bias<DT>(b1, 2 * k + 1, h)) << 16);
-          pk[hq][k] = c == 0 ? ml_gelu2<DT>(w, tab) : w;
-        }
-    }
-    if (c > 0) {
-      // ---- down(c - 1) with the activation of up(c)'s output between its MFMAs
-      const u32x4* nxt = c + 1 < NCH ? w1 + (size_t)((c + 1) * ML_WAVES + wave) * ML_KGC * 64 : w2 + (size_t)c * ML_KGC * 64;
-      ml_phase<DT, true>(accd, ring, w2 + (size_t)(c - 1) * ML_KGC * 64, nxt, dq0, dq1, pk, lane, tab);
-    }
-    if (c == 0) ML_STAMP(4);
-    fs_barrier();                                            // (A) every wave is done reading the previous chunk's image
-    // ---- this wave's 12th of the chunk image: a lane's 8 consecutive features after the half-wave exchange are piece
-    // 4 wave + 2 pr + h of row 32 hq + j
+      for (int k = 0; k < 8; ++k)
+        pk[hq][k] = (uint32_t)fs_from_f32<DT>(accu[hq][2 * k] + ml_bias<DT>(b1, 2 * k, h)) |
+                    ((uint32_t)fs_from_f32<DT>(accu[hq][2 * k + 1] + ml_bias<DT>(b1, 2 * k + 1, h)) << 16);
+  };
+  // this wave's 12th of a chunk image: a lane's 8 consecutive features after the half-wave exchange are piece
+  // 4 wave + 2 pr + h of row 32 hq + j (values 4 (2 pr + t) .. + 3 of the tile = pairs 2 (2 pr + t), 2 (2 pr + t) + 1)
+  auto write_chunk = [&]() {
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
       for (int hq = 0; hq < ML_QH; ++hq) {
-        // values 4 (2 pr + t) .. + 3 of the tile = pairs 2 (2 pr + t), 2 (2 pr + t) + 1
         const auto s0 = __builtin_amdgcn_permlane32_swap(pk[hq][4 * pr], pk[hq][4 * pr + 2], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(pk[hq][4 * pr + 1], pk[hq][4 * pr + 3], false, false);
         dimg[ml_unit(32 * hq + j, 4 * wave + 2 * pr + h)] = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
+  };
+  auto w1_block = [&](int c) { return w1 + (size_t)(c * ML_WAVES + wave) * ML_KGC * 64; };
+  auto w2_chunk = [&](int c) { return w2 + (size_t)c * ML_KGC * 64; };
+  // ---- up(0), then up(1) with chunk 0's activation between its MFMAs (one chunk only: the activation alone)
+  ml_phase<DT, false, true>(accu, ring, w1_block(0), NCH > 1 ? w1_block(1) : w2_chunk(0), xq0, xq1, pk, lane, tab);
+  ML_STAMP(3);
+  pack(0);
+  if constexpr (NCH > 1) {
+    ml_phase<DT, true, true>(accu, ring, w1_block(1), w2_chunk(0), xq0, xq1, pk, lane, tab);
+  } else {
+#pragma unroll
+    for (int hq = 0; hq < ML_QH; ++hq)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pk[hq][k] = ml_gelu2<DT>(pk[hq][k], tab);
+  }
+  ML_STAMP(4);
+  write_chunk();                                             // (nobody has read the chunk image yet: no barrier before it)
+  fs_barrier();                                              // (B) chunk 0's image is complete
+  ML_STAMP(5);
+#pragma unroll
+  for (int c = 1; c < NCH; ++c) {
+    pack(c);                                                 // up(c) ran before the previous chunk's image was written
+    // ---- down(c - 1) with the activation of up(c)'s output between its MFMAs
+    const u32x4* nxt = c + 1 < NCH ? w1_block(c + 1) : w2_chunk(c);
+    if (c == 1) ml_phase<DT, true, true>(accd, ring, w2_chunk(c - 1), nxt, dq0, dq1, pk, lane, tab);
+    else ml_phase<DT, true, false>(accd, ring, w2_chunk(c - 1), nxt, dq0, dq1, pk, lane, tab);
+    fs_barrier();                                            // (A) every wave is done reading the previous chunk's image
+    write_chunk();
     fs_barrier();                                            // (B) the chunk image is complete
-    if (c == 0) ML_STAMP(5);
+    if (c + 1 < NCH) ml_phase<DT, false, true>(accu, ring, w1_block(c + 1), w2_chunk(c), xq0, xq1, pk, lane, tab);   // ---- up(c + 1)
   }
   // ---- down(last); its bias is requested first
   const MlBias b2 = ml_load_bias(p.b2, wave);
-  ml_phase<DT, false>(accd, ring, w2 + (size_t)(NCH - 1) * ML_KGC * 64, nullptr, dq0, dq1, pk, lane, tab);
+  ml_phase<DT, false, NCH == 1>(accd, ring, w2_chunk(NCH - 1), nullptr, dq0, dq1, pk, lane, tab);
   fs_barrier();                                              // both images are dead
   // ---- projection output (+ bias, rounded) -> staging tile [96][H] where the images were
   unsigned char* stg = smem;
