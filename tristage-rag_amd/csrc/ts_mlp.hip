@@ -292,27 +292,8 @@ __global__ __launch_bounds__(64 * ML_WAVES) void mlp_ln_kernel(MlParams p) {
   // ---- down(last); its bias is requested first
   const MlBias b2 = ml_load_bias(p.b2, wave);
   ml_phase<DT, false, NCH == 1>(accd, ring, w2_chunk(NCH - 1), nullptr, dq0, dq1, pk, lane, tab);
-  fs_barrier();                                              // both images are dead
-  // ---- projection output (+ bias, rounded) -> staging tile [96][H] where the images were
-  unsigned char* stg = smem;
-#pragma unroll
-  for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-    for (int hq = 0; hq < ML_QH; ++hq) {
-      uint32_t w[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        uint16_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = fs_from_f32<DT>(accd[hq][4 * (2 * pr + t) + e] + ml_bias<DT>(b2, 4 * (2 * pr + t) + e, h));
-        w[t][0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        w[t][1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-      }
-      const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-      const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-      *reinterpret_cast<u32x4*>(stg + (size_t)(32 * hq + j) * ML_STAGE_STRIDE + 2 * (wave * 32 + 16 * pr + 8 * h)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-    }
-  ML_STAMP(6);
+  // (what the LayerNorm rows need from memory is requested HERE, behind the last phase's loads and before the barrier and
+  // the staging of the output: its latency passes under both)
   // ---- LayerNorm rows: half a wave per row, lane lir of the half owns chunks c * 32 + lir (as add_layernorm_kernel<.., 3, 32>)
   const int lir = j, sub = h;
   constexpr int H = ML_H;
@@ -338,6 +319,27 @@ __global__ __launch_bounds__(64 * ML_WAVES) void mlp_ln_kernel(MlParams p) {
       if (p.res) rs[it][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.res + base + (c * 32 + lir) * 4));   // read once
     }
   }
+  fs_barrier();                                              // both images are dead
+  // ---- projection output (+ bias, rounded) -> staging tile [96][H] where the images were
+  unsigned char* stg = smem;
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int hq = 0; hq < ML_QH; ++hq) {
+      uint32_t w[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        uint16_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fs_from_f32<DT>(accd[hq][4 * (2 * pr + t) + e] + ml_bias<DT>(b2, 4 * (2 * pr + t) + e, h));
+        w[t][0] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        w[t][1] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+      }
+      const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+      *reinterpret_cast<u32x4*>(stg + (size_t)(32 * hq + j) * ML_STAGE_STRIDE + 2 * (wave * 32 + 16 * pr + 8 * h)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+  ML_STAMP(6);
   fs_barrier();                                    // the staging tile is complete
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
