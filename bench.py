@@ -558,6 +558,10 @@ def main():
                 roof["measured_read_peak"] = round(pr["gbps_avg"], 1)
                 roof["measured_read_peak_best"] = round(pr["gbps_best"], 1)
                 roof["frac_of_measured_read_peak"] = round(achieved / pr["gbps_avg"], 4)
+                if achieved > pr["gbps_best"]:
+                    # seen on some boxes (up to 3 %): the pure-load probe runs slower than the scan that does the same loads AND
+                    # the arithmetic — a reference point of this box, not an upper bound
+                    roof["read_probe_note"] = "the probe's best pass is below the scan's rate on this box: a reference point, not a bound"
                 roof["read_probe"] = ("ts_index_read_probe: read-only kernel over this index's tiled corpus, same grid / "
                                       "block order / nt loads as the scan, 3 warm-up + 10 timed passes, HIP events")
             except Exception as e:
