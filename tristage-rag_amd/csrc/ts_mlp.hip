@@ -8,7 +8,7 @@
 // ts_linear_add_layernorm, ts_linear.hip) 0.62-0.68 ms.  Here the intermediate never leaves the CU:
 //   * 12 waves, wave w owns 32-feature block w of every 384-wide CHUNK of the intermediate (W1 block 12 c + w) and block w
 //     of the output (W2 block w, whose reduction is walked in the same chunks); both weights are streamed from L2 through
-//     ONE 8-deep register ring in the order the phases need them — the structure of ffn_stream_kernel / proj_ln_kernel;
+//     ONE register ring (6 deep: ML_RING) in the order the phases need them — the structure of ffn_stream_kernel / proj_ln_kernel;
 //   * up(c): 96 rows x 32 features from the LDS image of x (72 KiB, loaded once);  its output + bias, rounded, GELU, rounded,
 //     is written as the wave's 12th of the chunk's B-operand image (a second 72 KiB buffer) — a lane's 16-byte piece after
 //     the half-wave exchange IS a piece of that image;  down(c): the chunk image x W2's chunk c into the output accumulators;
