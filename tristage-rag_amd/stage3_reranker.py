@@ -259,7 +259,11 @@ class CrossEncoderReranker:
         wm = max(int(getattr(self.config, "many_width_multiple", 1) or 1), 1)
         bs = max(self.config.batch_size, self.config.many_batch_size)
         # packed batches (no padded position in the GEMMs, LayerNorms or GELU) whenever the written-out forward takes them
-        graph_one = P <= bs and P == whole and getattr(self.model, "use_hip_graph", False)    # one query's pairs: the replayed graph wins
+        # one query's pairs: the replayed graph wins — if they fit its largest bucket (a search_many batch of a few dozen queries
+        # is "all pairs in one batch" too, but thousands of rows: those go through the packed forward)
+        from .encoders import GraphedClassifier
+        graph_rows = GraphedClassifier.ROWS[-1]
+        graph_one = P <= min(bs, graph_rows) and P == whole and getattr(self.model, "use_hip_graph", False)
         packed = (wm == 1 and not graph_one and getattr(self.config, "many_packed", True) and hasattr(self.model, "packed_ok")
                   and self.model.packed_ok(int(self.config.max_length), min(max(bs, int(getattr(self.config, "many_packed_batch_size", bs))), P)))
         if packed:
