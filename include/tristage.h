@@ -362,7 +362,8 @@ int ts_linear_act(const void* w_tiled, const void* x, const void* bias, int32_t 
  * erf GELU(x)) applied as the rows are staged — BertIntermediate's activation folded into BertOutput, x being
  * the up projection's output BEFORE its activation (ts_linear_act with act 0): the activation costs no pass
  * of its own and its arithmetic runs beside this kernel's matrix instructions.  The roundings are those of
- * (gelu,) ts_linear_act, ts_add_layernorm, and so are the bits.  N a multiple of 32 up to 384 (a workgroup owns
+ * (gelu,) ts_linear_act, ts_add_layernorm, and for N > 128 so are the bits (below, the fp32 row statistics may
+ * differ in the last place: 1e-6).  N a multiple of 32 up to 384 (a workgroup owns
  * whole rows: the projection's output never goes to HBM), K a multiple of 384; pointers 16-byte aligned (bias 8). */
 int ts_linear_add_layernorm(const void* w_tiled, const void* x, const void* bias, const float* residual,
                             const float* gamma, const float* beta, float eps, int32_t dtype, int64_t M,
